@@ -1,0 +1,216 @@
+/*
+ * ws_hip.h -- C ABI of the MI355X (gfx950) watershed engine.
+ *
+ * This is the drop-in boundary for ONE path of smups/rustronomy-watershed v0.4.1:
+ * the segmenting / merging watershed transform and its seed finder.  The reference
+ * has no FFI of its own (it is a single Rust file); the seam this ABI replaces is
+ * the body of the private drivers behind the `Watershed<T>` trait.  Every entry
+ * point cites the reference interface it stands in for ("lib.rs:N" =
+ * src/lib.rs line N of the reference).  The Rust-side binding a maintainer would
+ * add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types;
+ *   - images are row-major u8 with a row stride in bytes (>= w);
+ *   - seeds are (row, col) pairs, two uint64_t per seed (Rust `(usize, usize)` repacked);
+ *   - host-side label planes are uint64_t (Rust `usize` on x86-64), row-major,
+ *     shape (h + 2e) x (w + 2e) with e = 1 when edge correction is on (the
+ *     reference's hook/transform outputs stay padded: lib.rs:1640-1666, 1812-1818);
+ *   - device-side label planes are uint32_t (colours are 1..=n_seeds < 2^32);
+ *   - every function returns WS_OK (0) or a negative ws_status; nothing aborts.
+ *   - a ws_ctx is single-threaded; different contexts may be used from different
+ *     host threads concurrently (the reference's structs are Send + Sync: lib.rs:65-67).
+ *
+ * Semantics fixed by the reference and reproduced here
+ *   - find_local_minima returns strict 8-neighbour local MAXIMA of the interior,
+ *     in row-major order (lib.rs:1178-1197);
+ *   - colours are 1..=n_seeds in slice order, later duplicates overwrite (lib.rs:1670-1677);
+ *   - only interior pixels are flooded (3x3 windows, lib.rs:220-222);
+ *   - levels run 0..=max_water_level inclusive (lib.rs:1689);
+ *   - where lakes of different colours meet, the reference picks a random neighbour
+ *     colour (lib.rs:249-253); this engine always takes the first coloured neighbour
+ *     in the reference's own order down,right,left,up (lib.rs:190, 245) -- a legal
+ *     outcome of the reference, and the only tie rule offered (WS_TIE_FIRST_DRLU);
+ *   - SegmentingWatershed::transform as written panics (lib.rs:1821 indexes the
+ *     level-0 hook result); ws_segment returns the intended result, the labels after
+ *     the last level (what transform_history(..).last() yields, lib.rs:1824-1835);
+ *   - merged-lake representative ids are arbitrary in the reference (sort/dedup order,
+ *     lib.rs:440-443, 508-541); this engine returns the canonical one: the smallest
+ *     seed colour whose seed pixel lies in the lake.
+ */
+#ifndef WS_HIP_H
+#define WS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_ABI_VERSION 1
+
+/* lib.rs:138-141 */
+#define WS_UNCOLOURED 0u
+#define WS_NORMAL_MAX 254u
+#define WS_ALWAYS_FILL 0u
+#define WS_NEVER_FILL 255u
+
+typedef enum ws_status {
+  WS_OK = 0,
+  WS_ERR_BAD_ARG = -1,       /* null pointer, stride < w, ... */
+  WS_ERR_MAX_TOO_HIGH = -2,  /* BuildErr::MaxToHigh, lib.rs:1026-1027 */
+  WS_ERR_MAX_TOO_LOW = -3,   /* BuildErr::MaxToLow,  lib.rs:1028-1029 */
+  WS_ERR_SEED_OOB = -4,      /* the reference panics: lib.rs:1366 / 1676 */
+  WS_ERR_HIP = -5,           /* a HIP runtime call failed; see ws_last_error */
+  WS_ERR_OOM = -6,           /* device or host allocation failed */
+  WS_ERR_NO_DEVICE = -7,
+  WS_ERR_CAPACITY = -8,      /* output buffer too small; *n_found still holds the true count */
+  WS_ERR_RING_OVERFLOW = -9, /* > 2^24-1 flood rings inside one level (needs > 16.7 M pixel corridor) */
+  WS_ERR_TOO_LARGE = -10,    /* plane has >= 2^32 pixels or seeds */
+  WS_ERR_UNSUPPORTED = -11
+} ws_status;
+
+typedef enum ws_engine {
+  WS_ENGINE_AUTO = 0,
+  /* all water levels fused: every pixel carries its (level, ring) arrival stamp and the
+   * flood is relaxed tile-by-tile in LDS; bit-identical to the sweep */
+  WS_ENGINE_FUSED = 1,
+  /* literal level sweep: one synchronous 4-neighbour flood step per launch, repeated
+   * until unchanged, for every level (lib.rs:1689-1748 one-to-one) */
+  WS_ENGINE_SWEEP = 2
+} ws_engine;
+
+#define WS_TIE_FIRST_DRLU 0
+
+/* The runtime options of TransformBuilder (lib.rs:908-923) as plain data. */
+typedef struct ws_options {
+  uint8_t max_water_level; /* lib.rs:950; valid 1..=254 */
+  uint8_t edge_correction; /* lib.rs:958; 0/1 */
+  uint8_t engine;          /* ws_engine */
+  uint8_t tie_rule;        /* WS_TIE_FIRST_DRLU */
+} ws_options;
+
+typedef struct ws_ctx ws_ctx;
+
+/* Counters of the last transform run on a context (the reference's `debug` PerfReport,
+ * lib.rs:640-696, restated for this engine). */
+typedef struct ws_stats {
+  uint32_t relax_passes;      /* fused engine: global relaxation passes launched */
+  uint32_t resolve_passes;    /* fused engine: global label-resolve passes launched */
+  uint32_t sweep_steps;       /* sweep engine: flood steps launched */
+  uint32_t merge_levels;      /* merging: levels with at least one union */
+  uint64_t tiles_run_relax;   /* tiles that actually did work, summed over passes */
+  uint64_t tiles_run_resolve;
+  float ms_relax;             /* HIP-event time per kernel class; filled only when */
+  float ms_resolve;           /* profiling is enabled with ws_ctx_set_profiling     */
+  float ms_sweep;
+  float ms_other;
+  float ms_total;             /* device time of the whole call between first and last launch */
+  uint32_t launches_relax;
+  uint32_t launches_resolve;
+  uint32_t launches_sweep;
+  uint32_t reserved;
+} ws_stats;
+
+/* HookCtx (lib.rs:844-862) as a C callback, invoked once per water level, in order.
+ * `labels` is a host plane valid only during the call.  The seeds slice of HookCtx is
+ * the caller's own seed list, so it is not passed back. */
+typedef void (*ws_level_cb)(void *user, uint8_t water_level, uint8_t max_water_level,
+                            const uint8_t *image, const uint64_t *labels, size_t h, size_t w);
+
+/* One lake of one level for transform_to_list (lib.rs:628-635, 1551-1561): the dense
+ * Vec<usize> of length h*w+1 per level is returned sparsely. */
+typedef struct ws_lake {
+  uint64_t colour;
+  uint64_t area;
+} ws_lake;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+int ws_abi_version(void);
+const char *ws_strerror(int status);
+
+/* Creates a context on HIP device `device` with its own stream. */
+int ws_ctx_create(int device, ws_ctx **out);
+/* Same, but all work is enqueued on the caller's hipStream_t (e.g. PyTorch's current
+ * stream), so the caller's events bracket the kernels. */
+int ws_ctx_create_on_stream(int device, void *hip_stream, ws_ctx **out);
+void ws_ctx_destroy(ws_ctx *ctx);
+const char *ws_last_error(const ws_ctx *ctx);
+int ws_ctx_set_profiling(ws_ctx *ctx, int enabled);
+int ws_ctx_get_stats(const ws_ctx *ctx, ws_stats *out);
+int ws_ctx_synchronize(ws_ctx *ctx);
+
+/* TransformBuilder::build_segmenting / build_merging validation (lib.rs:999-1004, 1026-1030). */
+int ws_options_default(ws_options *out);          /* lib.rs:936-946: max 254, no edge correction */
+int ws_options_validate(const ws_options *opt);
+
+/* ---- host-buffer entry points (what the Rust shim binds) ---------------------------- */
+
+/* WatershedUtils::find_local_minima (lib.rs:1178-1197).  Writes up to `cap` (row, col)
+ * pairs; *n_found receives the total.  WS_ERR_CAPACITY when cap is too small. */
+int ws_find_local_minima(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+                         uint64_t *out_rc, size_t cap, size_t *n_found);
+
+/* Watershed::transform for SegmentingWatershed (lib.rs:1810-1822, intended semantics). */
+int ws_segment(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+               const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
+               uint64_t *out_labels);
+
+/* Watershed::transform_with_hook for SegmentingWatershed (lib.rs:1638-1808): cb is called
+ * after every level 0..=max with the label plane of that level; transform_history
+ * (lib.rs:1824-1835) is this with a copying callback.  out_labels may be NULL. */
+int ws_segment_with_hook(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+                         const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
+                         ws_level_cb cb, void *user, uint64_t *out_labels);
+
+/* Watershed::transform_with_hook for MergingWatershed (lib.rs:1328-1522).  Labels passed
+ * to cb / written to out_labels carry canonical representatives (see top of file). */
+int ws_merge_with_hook(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+                       const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
+                       ws_level_cb cb, void *user, uint64_t *out_labels);
+
+/* Watershed::transform_to_list (lib.rs:1551-1561 merging, 1837-1847 segmenting), sparse:
+ * for level l the lakes with area > 0 are lakes[offsets[l] .. offsets[l+1]), sorted by
+ * colour; the uncoloured count (index 0 of the reference's vector) is uncoloured[l].
+ * offsets has max_water_level+2 entries, uncoloured max_water_level+1.
+ * *n_lakes receives the total number of records; WS_ERR_CAPACITY if cap is too small. */
+int ws_transform_to_list(ws_ctx *ctx, int merging, const uint8_t *img, size_t h, size_t w,
+                         size_t row_stride, const uint64_t *seeds_rc, size_t n_seeds,
+                         const ws_options *opt, ws_lake *lakes, size_t cap, size_t *n_lakes,
+                         uint64_t *offsets, uint64_t *uncoloured);
+
+/* MergingWatershed::transform is a stub in the reference (lib.rs:1524-1536): zeros with the
+ * interior set to 123, seeds ignored.  Reproduced for drop-in completeness. */
+int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out_labels);
+
+/* ---- device-resident entry points (inputs and outputs stay in HBM) ------------------- */
+
+/* d_img: device u8 plane; d_seeds_rc: device (row, col) pairs as uint32_t[2];
+ * d_labels: device uint32_t plane of the (padded, if edge correction) shape. */
+int ws_find_local_minima_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w,
+                                size_t row_stride, uint32_t *d_out_rc, size_t cap,
+                                size_t *n_found);
+int ws_segment_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                      const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
+                      uint32_t *d_labels);
+/* Merging transform, final canonical labels only. */
+int ws_merge_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                    const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
+                    uint32_t *d_labels);
+/* Arrival stamps of the last ws_segment_device / ws_merge_device call on this context:
+ * (level << 24 | ring), 0 for seeds, 0xFF000000 for never coloured.  Device pointer owned
+ * by the context, valid until the next call; shape as the label plane. */
+int ws_last_arrival_device(ws_ctx *ctx, const uint32_t **d_keys, size_t *h, size_t *w);
+/* Copies those stamps into the caller's device buffer of n_elems >= h*w words (stream ordered). */
+int ws_copy_last_arrival_device(ws_ctx *ctx, uint32_t *d_dst, size_t n_elems);
+
+/* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
+int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                           uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""ctypes binding of include/ws_hip.h (the C-ABI of the HIP engine).
+
+There is no CPU fallback: if the shared library has not been built this module raises,
+and every compute call needs a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libws_hip.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+szp = ctypes.POINTER(ctypes.c_size_t)
+sz = ctypes.c_size_t
+vp = ctypes.c_void_p
+
+WS_OK = 0
+WS_ERR_BAD_ARG = -1
+WS_ERR_MAX_TOO_HIGH = -2
+WS_ERR_MAX_TOO_LOW = -3
+WS_ERR_SEED_OOB = -4
+WS_ERR_HIP = -5
+WS_ERR_OOM = -6
+WS_ERR_NO_DEVICE = -7
+WS_ERR_CAPACITY = -8
+WS_ERR_RING_OVERFLOW = -9
+WS_ERR_TOO_LARGE = -10
+WS_ERR_UNSUPPORTED = -11
+
+WS_ENGINE_AUTO, WS_ENGINE_FUSED, WS_ENGINE_SWEEP = 0, 1, 2
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("max_water_level", ctypes.c_uint8), ("edge_correction", ctypes.c_uint8),
+                ("engine", ctypes.c_uint8), ("tie_rule", ctypes.c_uint8)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("relax_passes", ctypes.c_uint32), ("resolve_passes", ctypes.c_uint32),
+                ("sweep_steps", ctypes.c_uint32), ("merge_levels", ctypes.c_uint32),
+                ("tiles_run_relax", ctypes.c_uint64), ("tiles_run_resolve", ctypes.c_uint64),
+                ("ms_relax", ctypes.c_float), ("ms_resolve", ctypes.c_float), ("ms_sweep", ctypes.c_float),
+                ("ms_other", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("launches_relax", ctypes.c_uint32), ("launches_resolve", ctypes.c_uint32),
+                ("launches_sweep", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class Lake(ctypes.Structure):
+    _fields_ = [("colour", ctypes.c_uint64), ("area", ctypes.c_uint64)]
+
+
+LEVEL_CB = ctypes.CFUNCTYPE(None, vp, ctypes.c_uint8, ctypes.c_uint8, u8p, u64p, sz, sz)
+
+# every symbol include/ws_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ws_abi_version": (ctypes.c_int, []),
+    "ws_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "ws_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
+    "ws_ctx_create_on_stream": (ctypes.c_int, [ctypes.c_int, vp, ctypes.POINTER(vp)]),
+    "ws_ctx_destroy": (None, [vp]),
+    "ws_last_error": (ctypes.c_char_p, [vp]),
+    "ws_ctx_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ws_ctx_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),
+    "ws_ctx_synchronize": (ctypes.c_int, [vp]),
+    "ws_options_default": (ctypes.c_int, [ctypes.POINTER(Options)]),
+    "ws_options_validate": (ctypes.c_int, [ctypes.POINTER(Options)]),
+    "ws_find_local_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
+    "ws_segment": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_segment_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
+    "ws_merge_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
+    "ws_transform_to_list": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz,
+                                            szp, vp, vp]),
+    "ws_merge_transform_stub": (ctypes.c_int, [sz, sz, vp]),
+    "ws_find_local_minima_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
+    "ws_segment_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_last_arrival_device": (ctypes.c_int, [vp, ctypes.POINTER(vp), szp, szp]),
+    "ws_copy_last_arrival_device": (ctypes.c_int, [vp, vp, sz]),
+    "ws_random_field_device": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint64]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libws_hip.so (RTLD_LOCAL).  Raises if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = the library does not export the ABI
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

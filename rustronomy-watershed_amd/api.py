@@ -1,0 +1,359 @@
+"""Host-side mirror of the reference's public interface for the watershed path.
+
+Same names, argument meaning and error behaviour as rustronomy-watershed v0.4.1
+(`TransformBuilder`, `BuildErr`, `HookCtx`, `Watershed` trait methods, `WatershedUtils::
+find_local_minima`; "lib.rs:N" = src/lib.rs line N of the reference), implemented over the
+C-ABI in include/ws_hip.h.  All compute happens in the HIP engine; this file only moves
+numpy arrays across the boundary.
+
+Documented deviations:
+  * tie-break where lakes meet: first coloured neighbour in down,right,left,up order (the
+    reference picks at random among them, lib.rs:249-253);
+  * `SegmentingWatershed.transform` returns the labels after the last level (the reference
+    panics at lib.rs:1821);
+  * merged-lake ids are canonical (smallest seed colour in the lake) where the reference's are
+    arbitrary.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+UNCOLOURED = 0          # lib.rs:138
+NORMAL_MAX = 254        # lib.rs:139
+ALWAYS_FILL = 0         # lib.rs:140
+NEVER_FILL = 255        # lib.rs:141
+
+ENGINE_AUTO, ENGINE_FUSED, ENGINE_SWEEP = _ffi.WS_ENGINE_AUTO, _ffi.WS_ENGINE_FUSED, _ffi.WS_ENGINE_SWEEP
+
+
+class WatershedError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _ffi.lib().ws_strerror(status).decode()
+        super().__init__(f"{msg} ({status})" + (f": {detail}" if detail else ""))
+
+
+class BuildErr(ValueError):
+    """lib.rs:1051-1065"""
+
+
+class MaxToHigh(BuildErr):
+    def __init__(self, v):
+        self.value = v
+        super().__init__(f"Maximum water level set to {v}, which is higher than the maximum allowed value {NORMAL_MAX}")
+
+
+class MaxToLow(BuildErr):
+    def __init__(self, v):
+        self.value = v
+        # the reference's message names NEVER_FILL here (lib.rs:1062); kept verbatim in meaning
+        super().__init__(f"Maximum water level set to {v}, which is lower than the minimum allowed value {NEVER_FILL}")
+
+
+class SeedOutOfBounds(IndexError):
+    """the reference panics with an ndarray index error (lib.rs:1366 / 1676)"""
+
+
+class HookCtx:
+    """lib.rs:844-862"""
+    __slots__ = ("water_level", "max_water_level", "image", "colours", "seeds")
+
+    def __init__(self, water_level, max_water_level, image, colours, seeds):
+        self.water_level = water_level
+        self.max_water_level = max_water_level
+        self.image = image
+        self.colours = colours
+        self.seeds = seeds
+
+
+class Context:
+    """One ws_ctx: a HIP stream plus reusable device workspaces.  Not thread safe."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = ctypes.c_void_p()
+        L = _ffi.lib()
+        rc = (L.ws_ctx_create(device, ctypes.byref(self._h)) if stream is None
+              else L.ws_ctx_create_on_stream(device, ctypes.c_void_p(stream), ctypes.byref(self._h)))
+        if rc != _ffi.WS_OK:
+            self._h = ctypes.c_void_p()
+            raise WatershedError(rc, "ws_ctx_create")
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _ffi.lib().ws_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == _ffi.WS_OK:
+            return
+        detail = _ffi.lib().ws_last_error(self._h).decode()
+        if rc == _ffi.WS_ERR_SEED_OOB:
+            raise SeedOutOfBounds(detail)
+        raise WatershedError(rc, detail)
+
+    def set_profiling(self, on):
+        self.check(_ffi.lib().ws_ctx_set_profiling(self._h, int(on)))
+
+    def stats(self):
+        st = _ffi.Stats()
+        self.check(_ffi.lib().ws_ctx_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def synchronize(self):
+        self.check(_ffi.lib().ws_ctx_synchronize(self._h))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _as_image(img):
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError("input must be a 2-D uint8 array (ndarray::ArrayView2<u8>)")
+    if a.strides[1] != 1 or (a.shape[0] > 1 and a.strides[0] < a.shape[1]):
+        a = np.ascontiguousarray(a)          # the Rust shim calls as_standard_layout() likewise
+    stride = a.strides[0] if a.shape[0] > 1 else max(a.shape[1], 1)
+    return a, int(stride)
+
+
+def _as_seeds(seeds):
+    s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(-1, 2))
+    return s, int(s.shape[0])
+
+
+class TransformBuilder:
+    """lib.rs:908-1047.  `TransformBuilder()` is both `new()` and `default()`."""
+
+    def __init__(self):
+        self.max_water_level = NORMAL_MAX     # lib.rs:942
+        self.edge_correction = False          # lib.rs:943
+        self.wlvl_hook = None                 # lib.rs:944
+        self.engine = ENGINE_AUTO
+        self.context = None
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    @classmethod
+    def default(cls):
+        return cls()
+
+    def set_max_water_lvl(self, max_water_lvl):          # lib.rs:950
+        if not 0 <= int(max_water_lvl) <= 255:
+            raise OverflowError("max_water_lvl must fit a u8")
+        self.max_water_level = int(max_water_lvl)
+        return self
+
+    def enable_edge_correction(self):                    # lib.rs:958
+        self.edge_correction = True
+        return self
+
+    def set_wlvl_hook(self, hook):                       # lib.rs:967
+        self.wlvl_hook = hook
+        return self
+
+    # not in the reference: engine / context selection of this implementation
+    def set_engine(self, engine):
+        self.engine = engine
+        return self
+
+    def set_context(self, ctx):
+        self.context = ctx
+        return self
+
+    def _validate(self):
+        opt = _ffi.Options(self.max_water_level, int(self.edge_correction), self.engine, 0)
+        rc = _ffi.lib().ws_options_validate(ctypes.byref(opt))
+        if rc == _ffi.WS_ERR_MAX_TOO_HIGH:
+            raise MaxToHigh(self.max_water_level)         # lib.rs:1026-1027
+        if rc == _ffi.WS_ERR_MAX_TOO_LOW:
+            raise MaxToLow(self.max_water_level)          # lib.rs:1028-1029
+        if rc != _ffi.WS_OK:
+            raise WatershedError(rc, "ws_options_validate")
+        return opt
+
+    def build_segmenting(self):                           # lib.rs:1024-1046
+        return SegmentingWatershed(self._validate(), self.wlvl_hook, self.context)
+
+    def build_merging(self):                              # lib.rs:998-1020
+        return MergingWatershed(self._validate(), self.wlvl_hook, self.context)
+
+
+class WatershedUtils:
+    """lib.rs:1069-1198 (find_local_minima only: the pre-processor is outside this path)"""
+
+    def find_local_minima(self, img):
+        """Strict 8-neighbour local MAXIMA of the interior, row-major (lib.rs:1178-1197).
+        Returns an (n, 2) uint64 array of (row, col)."""
+        a, stride = _as_image(img)
+        h, w = a.shape
+        ctx = self._ctx()
+        cap = ((max(h, 1) - 1) // 2 + 1) * ((max(w, 1) - 1) // 2 + 1)
+        out = np.empty((max(cap, 1), 2), dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        rc = _ffi.lib().ws_find_local_minima(ctx.handle, a.ctypes.data, h, w, stride, out.ctypes.data, cap,
+                                             ctypes.byref(n))
+        ctx.check(rc)
+        return out[: n.value].copy()
+
+
+class _Transform(WatershedUtils):
+    _merging = False
+
+    def __init__(self, opt, hook, ctx):
+        self._opt = opt
+        self.max_water_level = opt.max_water_level
+        self.edge_correction = bool(opt.edge_correction)
+        self.wlvl_hook = hook
+        self._context = ctx
+
+    def _ctx(self):
+        return self._context if self._context is not None else default_context()
+
+    def _shape(self, a):
+        e = 2 if self.edge_correction else 0
+        return a.shape[0] + e, a.shape[1] + e
+
+    def _run_with_hook(self, img, seeds, hook, want_final):
+        a, stride = _as_image(img)
+        s, ns = _as_seeds(seeds)
+        h, w = a.shape
+        ph, pw = self._shape(a)
+        ctx = self._ctx()
+        results = []
+        seed_colours = None
+        cb = None
+        if hook is not None:
+            seed_colours = [(i + 1, (int(r), int(c))) for i, (r, c) in enumerate(s)]   # lib.rs:1671-1672
+
+            def _cb(_user, lvl, mx, pimg, plab, hh, ww):
+                image = np.ctypeslib.as_array(pimg, shape=(hh, ww))
+                colours = np.ctypeslib.as_array(plab, shape=(hh, ww))
+                results.append(hook(HookCtx(lvl, mx, image, colours, seed_colours)))
+            cb = _ffi.LEVEL_CB(_cb)
+        out = np.empty((ph, pw), dtype=np.uint64) if want_final else None
+        fn = _ffi.lib().ws_merge_with_hook if self._merging else _ffi.lib().ws_segment_with_hook
+        rc = fn(ctx.handle, a.ctypes.data, h, w, stride, s.ctypes.data, ns, ctypes.byref(self._opt),
+                ctypes.cast(cb, ctypes.c_void_p) if cb else None, None, out.ctypes.data if want_final else None)
+        ctx.check(rc)
+        return results, out
+
+    def transform_with_hook(self, input, seeds):          # lib.rs:1214
+        if self.wlvl_hook is None:
+            # the reference still runs the whole transform and returns an empty Vec (lib.rs:1796-1807)
+            self._run_with_hook(input, seeds, None, False)
+            return []
+        return self._run_with_hook(input, seeds, self.wlvl_hook, False)[0]
+
+    def transform_history(self, input, seeds):            # lib.rs:1233-1237, 1538-1549, 1824-1835
+        return self._run_with_hook(input, seeds, lambda ctx: (ctx.water_level, ctx.colours.copy()), False)[0]
+
+    def transform_to_list(self, input, seeds):            # lib.rs:1220-1224, 1551-1561, 1837-1847
+        """[(level, lake_sizes)] with lake_sizes a uint64 vector of length pixels+1 (lib.rs:630)."""
+        a, stride = _as_image(input)
+        s, ns = _as_seeds(seeds)
+        h, w = a.shape
+        ph, pw = self._shape(a)
+        ctx = self._ctx()
+        levels = self.max_water_level + 1
+        offsets = np.zeros(levels + 1, dtype=np.uint64)
+        unc = np.zeros(levels, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        cap = max(ns, 1) * 8
+        while True:
+            lakes = np.empty((cap, 2), dtype=np.uint64)
+            rc = _ffi.lib().ws_transform_to_list(ctx.handle, int(self._merging), a.ctypes.data, h, w, stride,
+                                                 s.ctypes.data, ns, ctypes.byref(self._opt), lakes.ctypes.data, cap,
+                                                 ctypes.byref(n), offsets.ctypes.data, unc.ctypes.data)
+            if rc == _ffi.WS_ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            ctx.check(rc)
+            break
+        out = []
+        for lvl in range(levels):
+            hist = np.zeros(ph * pw + 1, dtype=np.uint64)
+            lo, hi = int(offsets[lvl]), int(offsets[lvl + 1])
+            hist[lakes[lo:hi, 0].astype(np.int64)] = lakes[lo:hi, 1]
+            hist[0] = unc[lvl]
+            out.append((lvl, hist))
+        return out
+
+    def transform_to_list_sparse(self, input, seeds):
+        """Same content as transform_to_list without the dense h*w+1 vectors:
+        [(level, uncoloured, colours[], areas[])]."""
+        a, stride = _as_image(input)
+        s, ns = _as_seeds(seeds)
+        h, w = a.shape
+        ctx = self._ctx()
+        levels = self.max_water_level + 1
+        offsets = np.zeros(levels + 1, dtype=np.uint64)
+        unc = np.zeros(levels, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        cap = max(ns, 1) * 8
+        while True:
+            lakes = np.empty((cap, 2), dtype=np.uint64)
+            rc = _ffi.lib().ws_transform_to_list(ctx.handle, int(self._merging), a.ctypes.data, h, w, stride,
+                                                 s.ctypes.data, ns, ctypes.byref(self._opt), lakes.ctypes.data, cap,
+                                                 ctypes.byref(n), offsets.ctypes.data, unc.ctypes.data)
+            if rc == _ffi.WS_ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            ctx.check(rc)
+            break
+        return [(lvl, int(unc[lvl]), lakes[int(offsets[lvl]):int(offsets[lvl + 1]), 0].copy(),
+                 lakes[int(offsets[lvl]):int(offsets[lvl + 1]), 1].copy()) for lvl in range(levels)]
+
+
+class SegmentingWatershed(_Transform):
+    """lib.rs:1609-1849"""
+    _merging = False
+
+    def transform(self, input, seeds):                    # lib.rs:1810-1822 (intended semantics)
+        a, stride = _as_image(input)
+        s, ns = _as_seeds(seeds)
+        h, w = a.shape
+        ctx = self._ctx()
+        out = np.empty(self._shape(a), dtype=np.uint64)
+        rc = _ffi.lib().ws_segment(ctx.handle, a.ctypes.data, h, w, stride, s.ctypes.data, ns, ctypes.byref(self._opt),
+                                   out.ctypes.data)
+        ctx.check(rc)
+        return out
+
+
+class MergingWatershed(_Transform):
+    """lib.rs:1297-1562"""
+    _merging = True
+
+    def transform(self, input, _seeds=None):              # lib.rs:1524-1536: a stub in the reference
+        a, _ = _as_image(input)
+        out = np.empty(a.shape, dtype=np.uint64)
+        rc = _ffi.lib().ws_merge_transform_stub(a.shape[0], a.shape[1], out.ctypes.data)
+        if rc != _ffi.WS_OK:
+            raise WatershedError(rc)
+        return out
+
+    def transform_final(self, input, seeds):
+        """Not in the reference: the merged label plane after the last level."""
+        return self._run_with_hook(input, seeds, None, True)[1]

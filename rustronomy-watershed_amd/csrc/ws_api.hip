@@ -1,0 +1,640 @@
+// ws_api.hip -- the extern "C" boundary (include/ws_hip.h) and the host-side drivers.
+//
+// The drivers restate the reference's two transform_with_hook bodies (lib.rs:1328-1522,
+// 1638-1808) as launch sequences on one HIP stream.  There is no CPU fallback: every
+// entry point that computes needs a HIP device and fails with WS_ERR_NO_DEVICE /
+// WS_ERR_HIP otherwise.
+#include "../../include/ws_hip.h"
+#include "ws_common.hpp"
+#include "ws_merge.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace wsk;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+enum KClass { KC_RELAX = 0, KC_RESOLVE = 1, KC_SWEEP = 2, KC_OTHER = 3, KC_COUNT = 4 };
+
+struct TimedSpan {
+  hipEvent_t a, b;
+  int cls;
+};
+
+}  // namespace
+
+struct ws_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool profiling = false;
+  std::string err;
+  ws_stats stats{};
+
+  DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
+  uint32_t *pinned = nullptr;      // COUNTER_RING + 4 words of pinned host memory
+  hipEvent_t ring_ev[COUNTER_RING]{};
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<TimedSpan> spans;
+  std::vector<uint64_t> host64;    // hook staging
+  std::vector<uint8_t> host_img;
+  std::vector<uint32_t> host_seeds;
+  size_t last_h = 0, last_w = 0;
+  bool have_keys = false;
+  ws_merge_state merge;
+};
+
+namespace {
+
+// flags buffer layout (u32 words)
+constexpr int FLAG_COUNTERS = 0;                 // COUNTER_RING words
+constexpr int FLAG_OVERFLOW = COUNTER_RING;      // 1
+constexpr int FLAG_SEED_ERR = COUNTER_RING + 1;  // 1
+constexpr int FLAG_TILES_RELAX = COUNTER_RING + 2;
+constexpr int FLAG_TILES_RESOLVE = COUNTER_RING + 3;
+constexpr int FLAG_TOTAL = COUNTER_RING + 4;     // minima total
+constexpr int FLAG_WORDS = COUNTER_RING + 8;
+
+int fail(ws_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                              \
+  do {                                                                  \
+    hipError_t e_ = (call);                                             \
+    if (e_ != hipSuccess) return fail((ctx), e_ == hipErrorOutOfMemory ? WS_ERR_OOM : WS_ERR_HIP, #call, e_); \
+  } while (0)
+
+int ensure(ws_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return WS_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + (bytes >> 3) + 256;     // a little slack so near-equal sizes reuse
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return fail(c, WS_ERR_OOM, "hipMalloc", e); }
+  b.cap = want;
+  return WS_OK;
+}
+
+hipEvent_t next_event(ws_ctx *c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(e);
+  }
+  return c->ev_pool[c->ev_used++];
+}
+
+struct Span {
+  ws_ctx *c;
+  hipEvent_t a = nullptr, b = nullptr;
+  int cls;
+  Span(ws_ctx *ctx, int k) : c(ctx), cls(k) {
+    if (c->profiling) {
+      a = next_event(c);
+      b = next_event(c);
+      if (a) (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~Span() {
+    if (c->profiling && a && b) {
+      (void)hipEventRecord(b, c->stream);
+      c->spans.push_back({a, b, cls});
+    }
+  }
+};
+
+void stats_begin(ws_ctx *c) {
+  std::memset(&c->stats, 0, sizeof c->stats);
+  c->spans.clear();
+  c->ev_used = 0;
+  (void)hipEventRecord(c->ev_begin, c->stream);
+}
+
+int stats_end(ws_ctx *c) {
+  HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->ev_end));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.ms_total = ms;
+  for (const TimedSpan &s : c->spans) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) continue;
+    switch (s.cls) {
+      case KC_RELAX: c->stats.ms_relax += t; break;
+      case KC_RESOLVE: c->stats.ms_resolve += t; break;
+      case KC_SWEEP: c->stats.ms_sweep += t; break;
+      default: c->stats.ms_other += t; break;
+    }
+  }
+  return WS_OK;
+}
+
+int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *opt, size_t *ph, size_t *pw) {
+  if (!opt) return fail(c, WS_ERR_BAD_ARG, "options pointer is null");
+  int v = ws_options_validate(opt);
+  if (v != WS_OK) return fail(c, v, ws_strerror(v));
+  if (stride < w) return fail(c, WS_ERR_BAD_ARG, "row_stride < w");
+  const size_t e = opt->edge_correction ? 2 : 0;
+  *ph = h + e;
+  *pw = w + e;
+  if (*ph > 0x7FFFFFF0ull || *pw > 0x7FFFFFF0ull || (*ph) * (*pw) >= 0xFFFFFFFFull)
+    return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
+  return WS_OK;
+}
+
+// ---- fused engine ------------------------------------------------------------------------
+
+// Runs `launch(pass)` until a pass reports zero changed tile edges.  The next pass is
+// launched before the previous counter is read (one speculative pass, a no-op when the
+// previous one converged), so the host never stalls the stream between passes.
+template <class F>
+int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch) {
+  HIP_TRY(c, hipMemsetAsync(c->stamps.p, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_COUNTERS, 0, COUNTER_RING * sizeof(uint32_t), c->stream));
+  uint32_t pass = 0;
+  for (;; ++pass) {
+    HIP_TRY(c, launch(pass));
+    const int slot = pass % COUNTER_RING;
+    HIP_TRY(c, hipMemcpyAsync(&c->pinned[slot], d_flags + FLAG_COUNTERS + slot, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
+    if (pass >= 1) {
+      const int prev = (pass - 1) % COUNTER_RING;
+      HIP_TRY(c, hipEventSynchronize(c->ring_ev[prev]));
+      if (c->pinned[prev] == 0) break;
+    }
+  }
+  *passes_out = pass + 1;
+  return WS_OK;
+}
+
+int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
+              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels) {
+  const size_t n = (size_t)ph * pw;
+  const size_t ntiles = (size_t)tiles_of(pw) * tiles_of(ph);
+  int rc;
+  if ((rc = ensure(c, c->keys, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->stamps, (ntiles ? ntiles : 1) * 4 * 2 * sizeof(uint32_t)))) return rc;
+  uint32_t *keys = (uint32_t *)c->keys.p;
+  uint32_t *flags = (uint32_t *)c->flags.p;
+  uint32_t *stamps = (uint32_t *)c->stamps.p;
+  c->have_keys = false;
+
+  {
+    Span sp(c, KC_OTHER);
+    HIP_TRY(c, fill_u32(c->stream, keys, n, KEY_INF));
+    HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 4 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, n_seeds, ph, pw, d_labels, keys, flags + FLAG_SEED_ERR));
+  }
+  if (n == 0) return WS_OK;
+
+  rc = pass_loop(c, flags, ntiles, &c->stats.relax_passes, [&](uint32_t pass) {
+    Span sp(c, KC_RELAX);
+    return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps,
+                      flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX);
+  });
+  if (rc) return rc;
+  c->stats.launches_relax = c->stats.relax_passes;
+
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  if (c->pinned[COUNTER_RING]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+
+  rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
+    Span sp(c, KC_RESOLVE);
+    return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, flags + FLAG_COUNTERS,
+                        flags + FLAG_TILES_RESOLVE);
+  });
+  if (rc) return rc;
+  c->stats.launches_resolve = c->stats.resolve_passes;
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TILES_RELAX], flags + FLAG_TILES_RELAX, 2 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.tiles_run_relax = c->pinned[FLAG_TILES_RELAX];
+  c->stats.tiles_run_resolve = c->pinned[FLAG_TILES_RESOLVE];
+  c->have_keys = true;
+  c->last_h = ph;
+  c->last_w = pw;
+  return WS_OK;
+}
+
+// ---- sweep engine ------------------------------------------------------------------------
+
+// lib.rs:1689-1748 literally: for every level, flood steps until one colours nothing.
+// `after_level` (optional) sees the plane after each level's loop (the hook point).
+template <class F>
+int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
+              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, F after_level) {
+  const size_t n = (size_t)ph * pw;
+  int rc;
+  if ((rc = ensure(c, c->labels2, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  uint32_t *flags = (uint32_t *)c->flags.p;
+  uint32_t *cur = d_labels, *nxt = (uint32_t *)c->labels2.p;
+  c->have_keys = false;
+  HIP_TRY(c, hipMemsetAsync(cur, 0, n * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, scatter_seeds(c->stream, d_seeds, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+
+  for (uint32_t lvl = 0; lvl <= max_level; ++lvl) {
+    for (;;) {
+      if (n == 0) break;
+      {
+        Span sp(c, KC_SWEEP);
+        HIP_TRY(c, hipMemsetAsync(flags + FLAG_COUNTERS, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, flood_step(c->stream, d_img, stride, cur, nxt, ph, pw, lvl, flags + FLAG_COUNTERS));
+        c->stats.sweep_steps++;
+      }
+      HIP_TRY(c, hipMemcpyAsync(&c->pinned[0], flags + FLAG_COUNTERS, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      std::swap(cur, nxt);                 // an empty step copies the plane, so either buffer is current
+      if (c->pinned[0] == 0) break;        // lib.rs:1733-1735
+    }
+    rc = after_level(lvl, cur);
+    if (rc) return rc;
+  }
+  c->stats.launches_sweep = c->stats.sweep_steps;
+  if (cur != d_labels && n)
+    HIP_TRY(c, hipMemcpyAsync(d_labels, cur, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  return WS_OK;
+}
+
+int pick_engine(const ws_options *opt) {
+  return opt->engine == WS_ENGINE_SWEEP ? WS_ENGINE_SWEEP : WS_ENGINE_FUSED;
+}
+
+// Uploads a host image (optionally padded) and host seeds; returns device pointers.
+int stage_inputs(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                 size_t n_seeds, const ws_options *opt, size_t ph, size_t pw, const uint8_t **d_img,
+                 size_t *d_stride, const uint32_t **d_seeds) {
+  if ((!img && h * w) || (!seeds_rc && n_seeds)) return fail(c, WS_ERR_BAD_ARG, "null input pointer");
+  if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
+  int rc;
+  // seeds: the reference indexes the (padded) plane with the caller's coordinates and panics
+  // when they fall outside (lib.rs:1675-1677)
+  c->host_seeds.resize(2 * n_seeds);
+  for (size_t i = 0; i < n_seeds; ++i) {
+    const uint64_t r = seeds_rc[2 * i], cc = seeds_rc[2 * i + 1];
+    if (r >= ph || cc >= pw) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+    c->host_seeds[2 * i] = (uint32_t)r;
+    c->host_seeds[2 * i + 1] = (uint32_t)cc;
+  }
+  if ((rc = ensure(c, c->seeds, (n_seeds ? n_seeds : 1) * 2 * sizeof(uint32_t)))) return rc;
+  if (n_seeds)
+    HIP_TRY(c, hipMemcpyAsync(c->seeds.p, c->host_seeds.data(), n_seeds * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  *d_seeds = (const uint32_t *)c->seeds.p;
+
+  const size_t raw = (h * w ? h * w : 1);
+  if (opt->edge_correction) {
+    if ((rc = ensure(c, c->aux, raw))) return rc;
+    if ((rc = ensure(c, c->img, ph * pw))) return rc;
+    if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->aux.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, pad_image(c->stream, (const uint8_t *)c->aux.p, w, (int)h, (int)w, (uint8_t *)c->img.p));
+  } else {
+    if ((rc = ensure(c, c->img, raw))) return rc;
+    if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+  }
+  *d_img = (const uint8_t *)c->img.p;
+  *d_stride = pw;
+  return WS_OK;
+}
+
+// contiguous host copy of the (padded) image for the hook's `image` argument
+const uint8_t *hook_image(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, bool edge) {
+  if (!edge && stride == w) return img;
+  const size_t ph = h + (edge ? 2 : 0), pw = w + (edge ? 2 : 0), o = edge ? 1 : 0;
+  c->host_img.assign(ph * pw ? ph * pw : 1, 0);
+  for (size_t r = 0; r < h; ++r) std::memcpy(&c->host_img[(r + o) * pw + o], img + r * stride, w);
+  return c->host_img.data();
+}
+
+int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                 size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+  if (!c) return WS_ERR_BAD_ARG;
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = ph * pw;
+  const uint8_t *d_img;
+  size_t d_stride;
+  const uint32_t *d_seeds;
+  if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
+  stats_begin(c);
+  if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
+  uint32_t *d_labels = (uint32_t *)c->labels.p;
+  uint64_t *d_out64 = (uint64_t *)c->out64.p;
+  const uint8_t *himg = cb ? hook_image(c, img, h, w, stride, opt->edge_correction) : nullptr;
+  if (cb) c->host64.resize(n ? n : 1);
+
+  if (pick_engine(opt) == WS_ENGINE_SWEEP) {
+    rc = run_sweep(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, d_labels,
+                   [&](uint32_t lvl, const uint32_t *cur) -> int {
+                     if (!cb) return WS_OK;
+                     HIP_TRY(c, widen_labels(c->stream, cur, d_out64, n));
+                     HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+                     HIP_TRY(c, hipStreamSynchronize(c->stream));
+                     cb(user, (uint8_t)lvl, opt->max_water_level, himg, c->host64.data(), ph, pw);   // lib.rs:1796-1804
+                     return WS_OK;
+                   });
+    if (rc) return rc;
+  } else {
+    rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, d_labels);
+    if (rc) return rc;
+    if (cb) {
+      for (uint32_t lvl = 0; lvl <= opt->max_water_level; ++lvl) {
+        HIP_TRY(c, snapshot_level(c->stream, (const uint32_t *)c->keys.p, d_labels, d_out64, n, lvl));
+        HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        cb(user, (uint8_t)lvl, opt->max_water_level, himg, c->host64.data(), ph, pw);
+      }
+    }
+  }
+  if (out_labels && n) {
+    Span sp(c, KC_OTHER);
+    HIP_TRY(c, widen_labels(c->stream, d_labels, d_out64, n));
+    HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  return stats_end(c);
+}
+
+}  // namespace
+
+// ============================================================================ C ABI ====
+
+extern "C" {
+
+int ws_abi_version(void) { return WS_ABI_VERSION; }
+
+const char *ws_strerror(int status) {
+  switch (status) {
+    case WS_OK: return "ok";
+    case WS_ERR_BAD_ARG: return "bad argument";
+    case WS_ERR_MAX_TOO_HIGH: return "maximum water level higher than the maximum allowed value 254";
+    case WS_ERR_MAX_TOO_LOW: return "maximum water level lower than the minimum allowed value 1";
+    case WS_ERR_SEED_OOB: return "seed outside the label plane";
+    case WS_ERR_HIP: return "HIP runtime error";
+    case WS_ERR_OOM: return "out of memory";
+    case WS_ERR_NO_DEVICE: return "no HIP device";
+    case WS_ERR_CAPACITY: return "output buffer too small";
+    case WS_ERR_RING_OVERFLOW: return "ring counter overflow";
+    case WS_ERR_TOO_LARGE: return "input too large";
+    case WS_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+int ws_options_default(ws_options *out) {
+  if (!out) return WS_ERR_BAD_ARG;
+  out->max_water_level = WS_NORMAL_MAX;   // lib.rs:942
+  out->edge_correction = 0;               // lib.rs:943
+  out->engine = WS_ENGINE_AUTO;
+  out->tie_rule = WS_TIE_FIRST_DRLU;
+  return WS_OK;
+}
+
+int ws_options_validate(const ws_options *opt) {
+  if (!opt) return WS_ERR_BAD_ARG;
+  if (opt->max_water_level > WS_NORMAL_MAX) return WS_ERR_MAX_TOO_HIGH;     // lib.rs:1026-1027
+  if (opt->max_water_level <= WS_ALWAYS_FILL) return WS_ERR_MAX_TOO_LOW;     // lib.rs:1028-1029
+  if (opt->edge_correction > 1 || opt->engine > WS_ENGINE_SWEEP || opt->tie_rule != WS_TIE_FIRST_DRLU) return WS_ERR_BAD_ARG;
+  return WS_OK;
+}
+
+static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
+  if (!out) return WS_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return WS_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return WS_ERR_BAD_ARG;
+  ws_ctx *c = new (std::nothrow) ws_ctx();
+  if (!c) return WS_ERR_OOM;
+  c->device = device;
+  bool ok = hipSetDevice(device) == hipSuccess;
+  if (ok && own) ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  if (ok && !own) c->stream = (hipStream_t)stream;
+  c->own_stream = own;
+  ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
+  for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && ensure(c, c->flags, FLAG_WORDS * sizeof(uint32_t)) == WS_OK;
+  if (!ok) { ws_ctx_destroy(c); return WS_ERR_HIP; }
+  *out = c;
+  return WS_OK;
+}
+
+int ws_ctx_create(int device, ws_ctx **out) { return ctx_create(device, nullptr, true, out); }
+int ws_ctx_create_on_stream(int device, void *hip_stream, ws_ctx **out) { return ctx_create(device, hip_stream, false, out); }
+
+void ws_ctx_destroy(ws_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux})
+    if (b->p) (void)hipFree(b->p);
+  ws_merge_state_free(&c->merge);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < COUNTER_RING; ++i) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
+  if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *ws_last_error(const ws_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int ws_ctx_set_profiling(ws_ctx *c, int enabled) {
+  if (!c) return WS_ERR_BAD_ARG;
+  c->profiling = enabled != 0;
+  return WS_OK;
+}
+
+int ws_ctx_get_stats(const ws_ctx *c, ws_stats *out) {
+  if (!c || !out) return WS_ERR_BAD_ARG;
+  *out = c->stats;
+  return WS_OK;
+}
+
+int ws_ctx_synchronize(ws_ctx *c) {
+  if (!c) return WS_ERR_BAD_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WS_OK;
+}
+
+// ---- seeds --------------------------------------------------------------------------------
+
+int ws_find_local_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride,
+                                uint32_t *d_out_rc, size_t cap, size_t *n_found) {
+  if (!c || !n_found || (!d_img && h * w) || (!d_out_rc && cap)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (stride < w) return fail(c, WS_ERR_BAD_ARG, "row_stride < w");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
+  *n_found = 0;
+  if (h < 3 || w < 3) return WS_OK;                          // no 3x3 window (lib.rs:1183)
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t nseg = minima_segments((int)h, (int)w);
+  int rc;
+  if ((rc = ensure(c, c->counts, nseg * sizeof(uint32_t)))) return rc;
+  uint32_t *counts = (uint32_t *)c->counts.p;
+  uint32_t *flags = (uint32_t *)c->flags.p;
+  HIP_TRY(c, minima_count(c->stream, d_img, stride, (int)h, (int)w, counts));
+  HIP_TRY(c, exclusive_scan_u32(c->stream, counts, nseg, flags + FLAG_TOTAL));
+  HIP_TRY(c, minima_write(c->stream, d_img, stride, (int)h, (int)w, counts, d_out_rc, cap));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TOTAL], flags + FLAG_TOTAL, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n_found = c->pinned[FLAG_TOTAL];
+  if (*n_found > cap) return fail(c, WS_ERR_CAPACITY, "seed buffer too small");
+  return WS_OK;
+}
+
+int ws_find_local_minima(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, uint64_t *out_rc,
+                         size_t cap, size_t *n_found) {
+  if (!c || !n_found || (!img && h * w) || (!out_rc && cap)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (stride < w) return fail(c, WS_ERR_BAD_ARG, "row_stride < w");
+  *n_found = 0;
+  if (h < 3 || w < 3) return WS_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->img, h * w))) return rc;
+  // at most one strict maximum per 2x2 block of the interior
+  const size_t bound = ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1);
+  const size_t dcap = std::min(cap, bound);
+  if ((rc = ensure(c, c->seeds, (dcap ? dcap : 1) * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->out64, (dcap ? dcap : 1) * 2 * sizeof(uint64_t)))) return rc;
+  HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+  rc = ws_find_local_minima_device(c, (const uint8_t *)c->img.p, h, w, w, (uint32_t *)c->seeds.p, dcap, n_found);
+  if (rc != WS_OK && rc != WS_ERR_CAPACITY) return rc;
+  const size_t got = std::min(*n_found, dcap);
+  if (got) {
+    HIP_TRY(c, widen_pairs(c->stream, (const uint32_t *)c->seeds.p, (uint64_t *)c->out64.p, got * 2));
+    HIP_TRY(c, hipMemcpyAsync(out_rc, c->out64.p, got * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return rc;
+}
+
+// ---- segmenting ---------------------------------------------------------------------------
+
+int ws_segment(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+               size_t n_seeds, const ws_options *opt, uint64_t *out_labels) {
+  if (!out_labels) return fail(c, WS_ERR_BAD_ARG, "out_labels is null");
+  return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, out_labels);
+}
+
+int ws_segment_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                         size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+  return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels);
+}
+
+int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                      size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  if (!c) return WS_ERR_BAD_ARG;
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  if ((!d_img && h * w) || (!d_seeds_rc && n_seeds) || (!d_labels && ph * pw)) return fail(c, WS_ERR_BAD_ARG, "null device pointer");
+  if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  stats_begin(c);
+  const uint8_t *src = d_img;
+  size_t src_stride = stride;
+  if (opt->edge_correction) {
+    if ((rc = ensure(c, c->img, ph * pw))) return rc;
+    HIP_TRY(c, pad_image(c->stream, d_img, stride, (int)h, (int)w, (uint8_t *)c->img.p));
+    src = (const uint8_t *)c->img.p;
+    src_stride = pw;
+  }
+  if (pick_engine(opt) == WS_ENGINE_SWEEP)
+    rc = run_sweep(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, d_labels,
+                   [](uint32_t, const uint32_t *) { return (int)WS_OK; });
+  else
+    rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, d_labels);
+  if (rc) return rc;
+  return stats_end(c);
+}
+
+int ws_last_arrival_device(ws_ctx *c, const uint32_t **d_keys, size_t *h, size_t *w) {
+  if (!c || !d_keys || !h || !w) return WS_ERR_BAD_ARG;
+  if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call did not use the fused engine");
+  *d_keys = (const uint32_t *)c->keys.p;
+  *h = c->last_h;
+  *w = c->last_w;
+  return WS_OK;
+}
+
+int ws_copy_last_arrival_device(ws_ctx *c, uint32_t *d_dst, size_t n_elems) {
+  if (!c || !d_dst) return WS_ERR_BAD_ARG;
+  if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call did not use the fused engine");
+  const size_t n = c->last_h * c->last_w;
+  if (n_elems < n) return fail(c, WS_ERR_CAPACITY, "arrival buffer too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n) HIP_TRY(c, hipMemcpyAsync(d_dst, c->keys.p, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  return WS_OK;
+}
+
+int ws_random_field_device(ws_ctx *c, uint8_t *d_img, size_t h, size_t w, size_t stride, uint64_t seed) {
+  if (!c || (!d_img && h * w) || stride < w) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull) return fail(c, WS_ERR_TOO_LARGE, "too large");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, random_field(c->stream, d_img, stride, (int)h, (int)w, seed));
+  return WS_OK;
+}
+
+int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out) {
+  if (!out && h * w) return WS_ERR_BAD_ARG;
+  std::memset(out, 0, h * w * sizeof(uint64_t));                       // lib.rs:1529
+  if (h < 2 || w < 2) return WS_OK;
+  for (size_t r = 1; r + 1 < h; ++r)
+    for (size_t col = 1; col + 1 < w; ++col) out[r * w + col] = 123;   // lib.rs:1532
+  return WS_OK;
+}
+
+// ---- merging (ws_merge.hip) ------------------------------------------------------------------
+
+int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                    size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  (void)d_img; (void)h; (void)w; (void)stride; (void)d_seeds_rc; (void)n_seeds; (void)opt; (void)d_labels;
+  return fail(c, WS_ERR_UNSUPPORTED, "merging transform: not built yet");
+}
+
+int ws_merge_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                       size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+  (void)img; (void)h; (void)w; (void)stride; (void)seeds_rc; (void)n_seeds; (void)opt; (void)cb; (void)user; (void)out_labels;
+  return fail(c, WS_ERR_UNSUPPORTED, "merging transform: not built yet");
+}
+
+int ws_transform_to_list(ws_ctx *c, int merging, const uint8_t *img, size_t h, size_t w, size_t stride,
+                         const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *lakes, size_t cap,
+                         size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+  (void)merging; (void)img; (void)h; (void)w; (void)stride; (void)seeds_rc; (void)n_seeds; (void)opt; (void)lakes; (void)cap;
+  (void)n_lakes; (void)offsets; (void)uncoloured;
+  return fail(c, WS_ERR_UNSUPPORTED, "transform_to_list: not built yet");
+}
+
+}  // extern "C"

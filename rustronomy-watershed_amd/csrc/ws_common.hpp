@@ -1,0 +1,62 @@
+// ws_common.hpp -- shared definitions of the gfx950 watershed kernels.
+//
+// Arrival stamps.  The reference floods level by level and, inside a level, ring by
+// ring (lib.rs:1689-1748); a pixel coloured in ring r of level l gets the stamp
+//     key = (l << 24) | r          (r >= 1),
+// seeds carry key 0 (coloured before level 0, lib.rs:1675-1677) and pixels that are
+// never coloured carry KEY_INF.  In this encoding the reference's flood step
+// (lib.rs:224-231: flooded, uncoloured, a coloured 4-neighbour) becomes the fixpoint
+//     key(p) = max(base(p), 1 + min over the 4 neighbours q of key(q)),
+//     base(p) = (img[p] << 24) | 1 for interior pixels with img[p] <= max level,
+// and the colour is the colour of the first neighbour in down,right,left,up order
+// (lib.rs:190) whose key is smaller (lib.rs:237-248 with the col0 tie rule).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wsk {
+
+constexpr uint32_t KEY_INF = 0xFF000000u;   // level 255 can never open (NEVER_FILL, lib.rs:141)
+constexpr uint32_t RING_MASK = 0x00FFFFFFu;
+
+constexpr int TS = 64;        // tile side in pixels
+constexpr int LP = TS + 2;    // LDS tile side including the 1-px halo
+constexpr int STRIP = 16;     // rows per thread: 256 threads = 64 columns x 4 strips
+constexpr int NTHREADS = 256;
+constexpr int COUNTER_RING = 8;   // per-pass "edges changed" counters, reused cyclically
+
+struct Launch {
+  hipStream_t stream;
+};
+
+// --- launch wrappers (ws_kernels.hip) ---------------------------------------------------
+hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
+hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst);
+hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
+hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw,
+                         uint32_t *labels, uint32_t *keys, uint32_t *err_flag);
+hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
+hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
+                          size_t n, uint32_t level);
+
+hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
+                      int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
+                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run);
+hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
+                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run);
+
+hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
+                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);
+
+// local maxima: count per 1024-px row segment, scan, write
+size_t minima_segments(int h, int w);
+hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts);
+hipError_t exclusive_scan_u32(hipStream_t s, uint32_t *data, size_t n, uint32_t *total);
+hipError_t minima_write(hipStream_t s, const uint8_t *img, size_t stride, int h, int w,
+                        const uint32_t *offsets, uint32_t *out_rc, size_t cap);
+hipError_t widen_pairs(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n_values);
+
+inline int tiles_of(int n) { return (n + TS - 1) / TS; }
+
+}  // namespace wsk

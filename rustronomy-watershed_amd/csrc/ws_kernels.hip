@@ -1,0 +1,548 @@
+// ws_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the watershed engine.
+//
+// No MFMA anywhere: the path is integer min/max/compare work on u8 / u32 planes.  The
+// rules that matter are coalesced HBM rows, LDS-resident tiles, conflict-free LDS rows
+// (lanes run along x) and wave-level reductions for convergence.
+#include "ws_common.hpp"
+
+namespace wsk {
+
+// ---------------------------------------------------------------- small utilities ----
+
+__global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) p[i] = v;
+}
+
+hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
+  k_fill_u32<<<blocks, 256, 0, s>>>(p, n, v);
+  return hipGetLastError();
+}
+
+// lib.rs:1650-1666: copy the input into the centre of a zeroed (h+2) x (w+2) plane.
+__global__ void k_pad_image(const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst) {
+  const int pw = w + 2, ph = h + 2;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)ph * pw, step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const int r = (int)(i / pw), c = (int)(i % pw);
+    const bool inside = r >= 1 && r <= h && c >= 1 && c <= w;
+    dst[i] = inside ? src[(size_t)(r - 1) * src_stride + (c - 1)] : (uint8_t)0;
+  }
+}
+
+hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst) {
+  const size_t n = (size_t)(h + 2) * (w + 2);
+  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
+  k_pad_image<<<blocks, 256, 0, s>>>(src, src_stride, h, w, dst);
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void k_random_field(uint8_t *img, size_t stride, int h, int w, uint64_t base) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)h * w, step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const size_t r = i / (size_t)w, c = i % (size_t)w;
+    img[r * stride + c] = (uint8_t)(mix64(base + i) % 254u);
+  }
+}
+
+hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed) {
+  const size_t n = (size_t)h * w;
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 16384 ? (n + 1023) / 1024 : 16384);
+  k_random_field<<<blocks, 256, 0, s>>>(img, stride, h, w, seed << 40);
+  return hipGetLastError();
+}
+
+// lib.rs:1670-1677: colour i+1 at seed i; a later duplicate overwrites an earlier one
+// (atomicMax keeps the largest index = the last writer of the sequential loop).
+__global__ void k_scatter_seeds(const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
+                                uint32_t *keys, uint32_t *err_flag) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint32_t r = seeds_rc[2 * i], c = seeds_rc[2 * i + 1];
+    if (r >= (uint32_t)ph || c >= (uint32_t)pw) { atomicExch(err_flag, 1u); continue; }
+    const size_t p = (size_t)r * pw + c;
+    atomicMax(&labels[p], (uint32_t)(i + 1));
+    if (keys) keys[p] = 0u;
+  }
+}
+
+hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw,
+                         uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n, ph, pw, labels, keys, err_flag);
+  return hipGetLastError();
+}
+
+__global__ void k_widen(const uint32_t *src, uint64_t *dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) dst[i] = src[i];
+}
+
+hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
+  k_widen<<<blocks, 256, 0, s>>>(src, dst, n);
+  return hipGetLastError();
+}
+
+hipError_t widen_pairs(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n_values) {
+  return widen_labels(s, src, dst, n_values);
+}
+
+// Label plane as the reference's hook sees it after `level` (lib.rs:1796-1804): a pixel
+// is coloured once its arrival level is <= level; segmenting colours never change later.
+__global__ void k_snapshot(const uint32_t *keys, const uint32_t *labels, uint64_t *dst, size_t n,
+                           uint32_t level) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint32_t k = keys[i];
+    dst[i] = (k != KEY_INF && (k >> 24) <= level) ? (uint64_t)labels[i] : 0ull;
+  }
+}
+
+hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
+                          size_t n, uint32_t level) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
+  k_snapshot<<<blocks, 256, 0, s>>>(keys, labels, dst, n, level);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------- fused engine: relaxation ----
+//
+// One workgroup = one 64x64 tile held in LDS with its 1-px halo.  256 threads: lane = x
+// (so every LDS row access is 64 consecutive dwords: conflict free), wave = 16-row strip.
+// Each thread keeps its 16 stamps and 16 bases in registers and sweeps its strip down
+// then up (Gauss-Seidel inside the strip), reading left/right/strip-end neighbours from
+// LDS.  The recurrence is monotone, so any update order reaches the same fixpoint; the
+// tile iterates until a full sweep changes nothing (workgroup OR-reduction), then writes
+// the changed stamps back.  Tiles whose halo did not change since their last run exit at
+// once (edge stamps); the host stops when a pass changes no tile edge.
+
+__device__ __forceinline__ bool tile_must_run(const uint32_t *stamps_prev, int tx, int ty, int tilesX,
+                                              int tilesY, uint32_t pass) {
+  if (pass == 0) return true;
+  // stamp layout per tile: 0 top, 1 bottom, 2 left, 3 right; value = pass+1 of the writer
+  const int t = ty * tilesX + tx;
+  bool run = false;
+  if (ty > 0) run |= stamps_prev[(size_t)(t - tilesX) * 4 + 1] == pass;
+  if (ty + 1 < tilesY) run |= stamps_prev[(size_t)(t + tilesX) * 4 + 0] == pass;
+  if (tx > 0) run |= stamps_prev[(size_t)(t - 1) * 4 + 3] == pass;
+  if (tx + 1 < tilesX) run |= stamps_prev[(size_t)(t + 1) * 4 + 2] == pass;
+  return run;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_relax(const uint8_t *__restrict__ img, size_t img_stride,
+                                                    uint32_t *keys, int H, int W, int tilesX, int tilesY,
+                                                    uint32_t max_level, uint32_t pass, uint32_t *stamps,
+                                                    uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run) {
+  __shared__ uint32_t sT[LP][LP];
+  __shared__ uint32_t s_edges;
+
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const size_t ntiles = (size_t)tilesX * tilesY;
+  const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
+  uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(pass + 1) % COUNTER_RING] = 0;
+  if (!tile_must_run(stamps_prev, tile_x, tile_y, tilesX, tilesY, pass)) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, strip = tid >> 6;
+  const int x0 = tile_x * TS, y0 = tile_y * TS;
+  if (tid == 0) { s_edges = 0; atomicAdd(tiles_run, 1u); }
+
+  // tile + halo -> LDS (out-of-image = never coloured)
+  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
+    const int ly = idx / LP, lx = idx - ly * LP;
+    const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+    uint32_t v = KEY_INF;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = keys[(size_t)gy * W + gx];
+    sT[ly][lx] = v;
+  }
+
+  // this thread's column strip: bases in registers
+  const int gx = x0 + lane;
+  const int gy0 = y0 + strip * STRIP;
+  uint32_t base[STRIP], own[STRIP];
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) {
+    const int gy = gy0 + i;
+    uint32_t b = KEY_INF;
+    // only interior pixels are ever flooded (3x3 windows: lib.rs:220-222)
+    if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
+      const uint32_t v = img[(size_t)gy * img_stride + gx];
+      if (v <= max_level) b = (v << 24) | 1u;               // lib.rs:224: img <= level
+    }
+    base[i] = b;
+  }
+  __syncthreads();
+  const int lx = lane + 1, ly0 = strip * STRIP + 1;
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) own[i] = sT[ly0 + i][lx];
+
+  uint32_t changed_mask = 0;
+  for (;;) {
+    int changed = 0;
+    // downward sweep
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const uint32_t l = sT[ly0 + i][lx - 1], r = sT[ly0 + i][lx + 1];
+      const uint32_t u = (i == 0) ? sT[ly0 - 1][lx] : own[i - 1];
+      const uint32_t d = (i == STRIP - 1) ? sT[ly0 + STRIP][lx] : own[i + 1];
+      const uint32_t m = min(min(l, r), min(u, d));
+      const uint32_t n = min(own[i], max(base[i], m + 1u));
+      if (n != own[i]) { own[i] = n; sT[ly0 + i][lx] = n; changed = 1; changed_mask |= 1u << i; }
+    }
+    // upward sweep
+#pragma unroll
+    for (int i = STRIP - 1; i >= 0; --i) {
+      const uint32_t l = sT[ly0 + i][lx - 1], r = sT[ly0 + i][lx + 1];
+      const uint32_t u = (i == 0) ? sT[ly0 - 1][lx] : own[i - 1];
+      const uint32_t d = (i == STRIP - 1) ? sT[ly0 + STRIP][lx] : own[i + 1];
+      const uint32_t m = min(min(l, r), min(u, d));
+      const uint32_t n = min(own[i], max(base[i], m + 1u));
+      if (n != own[i]) { own[i] = n; sT[ly0 + i][lx] = n; changed = 1; changed_mask |= 1u << i; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+
+  // write back what changed; coalesced rows of 64 dwords per wave
+  uint32_t ovf = 0;
+  if (gx < W) {
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const int gy = gy0 + i;
+      if ((changed_mask >> i) & 1u) {
+        if (gy < H) keys[(size_t)gy * W + gx] = own[i];
+        // a finite non-seed stamp with ring 0 can only come from a ring-field carry
+        ovf |= (own[i] != 0u && own[i] < KEY_INF && (own[i] & RING_MASK) == 0u);
+      }
+    }
+  }
+  if (ovf) atomicExch(overflow, 1u);
+
+  uint32_t e = 0;
+  if (strip == 0 && (changed_mask & 1u)) e |= 1u;                         // top row
+  if (strip == (NTHREADS / 64) - 1 && (changed_mask >> (STRIP - 1))) e |= 2u;  // bottom row
+  if (lane == 0 && changed_mask) e |= 4u;                                 // left column
+  if (lane == 63 && changed_mask) e |= 8u;                                // right column
+  if (e) atomicOr(&s_edges, e);
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t ed = s_edges;
+    if (ed) {
+      const size_t t = (size_t)tile_y * tilesX + tile_x;
+      if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
+      if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
+      if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
+      if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
+      atomicAdd(&counters[pass % COUNTER_RING], 1u);
+    }
+  }
+}
+
+hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
+                      int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
+                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run) {
+  const int tx = tiles_of(w), ty = tiles_of(h);
+  k_relax<<<tx * ty, NTHREADS, 0, s>>>(img, img_stride, keys, h, w, tx, ty, max_level, pass, stamps,
+                                       counters, overflow, tiles_run);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------- fused engine: label resolve ----
+//
+// With the stamps final, the colour of a pixel is the colour of its parent: the first
+// neighbour in down,right,left,up order (lib.rs:190) that was coloured strictly earlier
+// (lib.rs:237-248, col0).  Parents form a forest rooted at the seeds.  A tile computes the
+// parent direction of its 16 pixels per thread once, then pulls labels along the forest
+// until nothing changes; labels only ever go 0 -> final, so a coloured pixel is done.
+
+__global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict__ keys, uint32_t *labels,
+                                                      int H, int W, int tilesX, int tilesY, uint32_t pass,
+                                                      uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run) {
+  __shared__ uint32_t sB[LP][LP];
+  __shared__ uint32_t s_edges;
+
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const size_t ntiles = (size_t)tilesX * tilesY;
+  const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
+  uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(pass + 1) % COUNTER_RING] = 0;
+  if (!tile_must_run(stamps_prev, tile_x, tile_y, tilesX, tilesY, pass)) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, strip = tid >> 6;
+  const int x0 = tile_x * TS, y0 = tile_y * TS;
+  const int lx = lane + 1, ly0 = strip * STRIP + 1;
+  const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
+  if (tid == 0) { s_edges = 0; atomicAdd(tiles_run, 1u); }
+
+  // phase 1: stamps -> LDS, parent directions -> registers
+  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
+    const int ly = idx / LP, lxx = idx - ly * LP;
+    const int gy = y0 - 1 + ly, gxx = x0 - 1 + lxx;
+    uint32_t v = KEY_INF;
+    if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) v = keys[(size_t)gy * W + gxx];
+    sB[ly][lxx] = v;
+  }
+  __syncthreads();
+  uint32_t dirs = 0;      // 2 bits per pixel: 0 down, 1 right, 2 left, 3 up
+  uint32_t has_parent = 0;
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) {
+    const uint32_t k = sB[ly0 + i][lx];
+    if (k != 0u && k != KEY_INF) {
+      const uint32_t d = sB[ly0 + i + 1][lx], r = sB[ly0 + i][lx + 1];
+      const uint32_t l = sB[ly0 + i][lx - 1];
+      const uint32_t dir = d < k ? 0u : (r < k ? 1u : (l < k ? 2u : 3u));   // at a fixpoint one of the four is < k
+      dirs |= dir << (2 * i);
+      has_parent |= 1u << i;
+    }
+  }
+  __syncthreads();
+
+  // phase 2: labels -> the same LDS tile
+  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
+    const int ly = idx / LP, lxx = idx - ly * LP;
+    const int gy = y0 - 1 + ly, gxx = x0 - 1 + lxx;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) v = labels[(size_t)gy * W + gxx];
+    sB[ly][lxx] = v;
+  }
+  __syncthreads();
+  uint32_t own[STRIP];
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) own[i] = sB[ly0 + i][lx];
+
+  uint32_t todo = 0;      // pixels with a parent and no colour yet
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) todo |= (((has_parent >> i) & 1u) && own[i] == 0u) ? (1u << i) : 0u;
+  uint32_t changed_mask = 0;
+
+  for (;;) {
+    int changed = 0;
+    if (todo) {
+#pragma unroll
+      for (int i = 0; i < STRIP; ++i) {
+        if ((todo >> i) & 1u) {
+          const uint32_t dir = (dirs >> (2 * i)) & 3u;
+          const uint32_t vd = (i == STRIP - 1) ? sB[ly0 + STRIP][lx] : own[i + 1];
+          const uint32_t vu = (i == 0) ? sB[ly0 - 1][lx] : own[i - 1];
+          const uint32_t vr = sB[ly0 + i][lx + 1], vl = sB[ly0 + i][lx - 1];
+          const uint32_t src = dir == 0u ? vd : (dir == 1u ? vr : (dir == 2u ? vl : vu));
+          if (src) { own[i] = src; sB[ly0 + i][lx] = src; todo &= ~(1u << i); changed = 1; changed_mask |= 1u << i; }
+        }
+      }
+#pragma unroll
+      for (int i = STRIP - 1; i >= 0; --i) {
+        if ((todo >> i) & 1u) {
+          const uint32_t dir = (dirs >> (2 * i)) & 3u;
+          const uint32_t vd = (i == STRIP - 1) ? sB[ly0 + STRIP][lx] : own[i + 1];
+          const uint32_t vu = (i == 0) ? sB[ly0 - 1][lx] : own[i - 1];
+          const uint32_t vr = sB[ly0 + i][lx + 1], vl = sB[ly0 + i][lx - 1];
+          const uint32_t src = dir == 0u ? vd : (dir == 1u ? vr : (dir == 2u ? vl : vu));
+          if (src) { own[i] = src; sB[ly0 + i][lx] = src; todo &= ~(1u << i); changed = 1; changed_mask |= 1u << i; }
+        }
+      }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+
+  if (gx < W) {
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const int gy = gy0 + i;
+      if (((changed_mask >> i) & 1u) && gy < H) labels[(size_t)gy * W + gx] = own[i];
+    }
+  }
+  uint32_t e = 0;
+  if (strip == 0 && (changed_mask & 1u)) e |= 1u;
+  if (strip == (NTHREADS / 64) - 1 && (changed_mask >> (STRIP - 1))) e |= 2u;
+  if (lane == 0 && changed_mask) e |= 4u;
+  if (lane == 63 && changed_mask) e |= 8u;
+  if (e) atomicOr(&s_edges, e);
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t ed = s_edges;
+    if (ed) {
+      const size_t t = (size_t)tile_y * tilesX + tile_x;
+      if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
+      if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
+      if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
+      if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
+      atomicAdd(&counters[pass % COUNTER_RING], 1u);
+    }
+  }
+}
+
+hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
+                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run) {
+  const int tx = tiles_of(w), ty = tiles_of(h);
+  k_resolve<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ty, pass, stamps, counters, tiles_run);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------ sweep engine: one flood step -------
+//
+// lib.rs:196-257 one-to-one: every interior pixel that is flooded (img <= level),
+// uncoloured and has a coloured 4-neighbour takes the first coloured neighbour in
+// down,right,left,up order; reads only the previous plane (lin), writes the next (lout).
+
+__global__ __launch_bounds__(256) void k_flood_step(const uint8_t *__restrict__ img, size_t img_stride,
+                                                    const uint32_t *__restrict__ lin, uint32_t *__restrict__ lout,
+                                                    int H, int W, uint32_t level, uint32_t *counter) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int coloured = 0;
+  if (x < W && y < H) {
+    const size_t p = (size_t)y * W + x;
+    uint32_t v = lin[p];
+    if (v == 0u && y >= 1 && y < H - 1 && x >= 1 && x < W - 1 && img[(size_t)y * img_stride + x] <= level) {
+      const uint32_t d = lin[p + W], r = lin[p + 1], l = lin[p - 1], u = lin[p - W];
+      v = d ? d : (r ? r : (l ? l : u));
+      coloured = v != 0u;
+    }
+    lout[p] = v;
+  }
+  if (__syncthreads_or(coloured) && threadIdx.x == 0) atomicAdd(counter, 1u);
+}
+
+hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
+                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter) {
+  dim3 grid((w + 63) / 64, (h + 3) / 4);
+  k_flood_step<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------- find_local_minima --------
+//
+// lib.rs:1178-1197: interior pixels whose 8 neighbours are all strictly smaller, emitted
+// in row-major order.  Two passes over 1024-pixel row segments (256 threads x 4 px):
+// count, exclusive scan of the segment counts, then an ordered write.
+
+constexpr int SEG = 1024;
+
+size_t minima_segments(int h, int w) { return (size_t)h * ((w + SEG - 1) / SEG); }
+
+__device__ __forceinline__ uint32_t maxima_mask4(const uint8_t *img, size_t stride, int H, int W, int y, int x0) {
+  // bit k set when pixel (y, x0+k) is a strict 8-neighbour maximum of the interior
+  uint32_t m = 0;
+  if (y < 1 || y >= H - 1) return 0;
+  const uint8_t *rm = img + (size_t)(y - 1) * stride, *r0 = img + (size_t)y * stride, *rp = img + (size_t)(y + 1) * stride;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + k;
+    if (x >= 1 && x < W - 1) {
+      const uint8_t v = r0[x];
+      const bool ok = rm[x - 1] < v && rm[x] < v && rm[x + 1] < v && r0[x - 1] < v && r0[x + 1] < v &&
+                      rp[x - 1] < v && rp[x] < v && rp[x + 1] < v;
+      m |= ok ? (1u << k) : 0u;
+    }
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_minima_count(const uint8_t *__restrict__ img, size_t stride, int H, int W,
+                                                      int segs, uint32_t *counts) {
+  __shared__ uint32_t s_sum;
+  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  const uint32_t m = maxima_mask4(img, stride, H, W, y, seg * SEG + threadIdx.x * 4);
+  uint32_t c = __popc(m);
+  // wave reduction, then one LDS atomic per wave
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_sum;
+}
+
+hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts) {
+  const int segs = (w + SEG - 1) / SEG;
+  if (h == 0 || w == 0) return hipSuccess;
+  k_minima_count<<<h * segs, 256, 0, s>>>(img, stride, h, w, segs, counts);
+  return hipGetLastError();
+}
+
+// single-workgroup exclusive scan (n up to a few million entries); total -> *total
+__global__ __launch_bounds__(1024) void k_exclusive_scan(uint32_t *data, size_t n, uint32_t *total) {
+  __shared__ uint32_t s_part[1024];
+  const int t = threadIdx.x;
+  const size_t chunk = (n + 1023) / 1024;
+  const size_t b = (size_t)t * chunk, e = b + chunk < n ? b + chunk : n;
+  uint32_t sum = 0;
+  for (size_t i = b; i < e; ++i) sum += data[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
+    uint32_t v = t >= off ? s_part[t - off] : 0u;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0u;
+  for (size_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+  if (t == 1023) *total = s_part[1023];
+}
+
+hipError_t exclusive_scan_u32(hipStream_t s, uint32_t *data, size_t n, uint32_t *total) {
+  k_exclusive_scan<<<1, 1024, 0, s>>>(data, n, total);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict__ img, size_t stride, int H, int W,
+                                                      int segs, const uint32_t *__restrict__ offsets,
+                                                      uint32_t *out_rc, size_t cap) {
+  __shared__ uint32_t s_wave[4];
+  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
+  const int x0 = seg * SEG + threadIdx.x * 4;
+  const uint32_t m = maxima_mask4(img, stride, H, W, y, x0);
+  const uint32_t c = __popc(m);
+  // exclusive prefix of c inside the wave, then across the 4 waves
+  uint32_t incl = c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t wave_base = 0;
+  for (int k = 0; k < wave; ++k) wave_base += s_wave[k];
+  size_t pos = (size_t)offsets[blockIdx.x] + wave_base + (incl - c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if ((m >> k) & 1u) {
+      if (pos < cap) { out_rc[2 * pos] = (uint32_t)y; out_rc[2 * pos + 1] = (uint32_t)(x0 + k); }
+      ++pos;
+    }
+  }
+}
+
+hipError_t minima_write(hipStream_t s, const uint8_t *img, size_t stride, int h, int w,
+                        const uint32_t *offsets, uint32_t *out_rc, size_t cap) {
+  const int segs = (w + SEG - 1) / SEG;
+  if (h == 0 || w == 0) return hipSuccess;
+  k_minima_write<<<h * segs, 256, 0, s>>>(img, stride, h, w, segs, offsets, out_rc, cap);
+  return hipGetLastError();
+}
+
+}  // namespace wsk

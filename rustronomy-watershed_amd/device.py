@@ -1,0 +1,84 @@
+"""Device-resident entry points over PyTorch-ROCm tensors.
+
+PyTorch is plumbing here (HBM allocations, the current HIP stream, torch.distributed);
+all compute is the HIP engine behind include/ws_hip.h.  Tensors hold raw bits: label and
+seed planes are int32 tensors carrying the uint32 values of the C ABI.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+from .api import Context, ENGINE_AUTO
+
+
+class DeviceEngine:
+    def __init__(self, device_index=0, engine=ENGINE_AUTO):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceEngine needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        # enqueue on torch's current stream so torch events bracket the engine's kernels
+        self.stream = torch.cuda.current_stream(self.device)
+        self.ctx = Context(device_index, stream=self.stream.cuda_stream)
+        self.engine = engine
+
+    def options(self, max_level=254, edge=False, engine=None):
+        return _ffi.Options(max_level, int(edge), self.engine if engine is None else engine, 0)
+
+    def random_field(self, h, w, seed):
+        img = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        self.ctx.check(_ffi.lib().ws_random_field_device(self.ctx.handle, img.data_ptr(), h, w, w, seed))
+        return img
+
+    def find_local_minima(self, img):
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        h, w = img.shape
+        cap = ((max(h, 1) - 1) // 2 + 1) * ((max(w, 1) - 1) // 2 + 1)
+        out = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=self.device)
+        n = ctypes.c_size_t(0)
+        self.ctx.check(_ffi.lib().ws_find_local_minima_device(self.ctx.handle, img.data_ptr(), h, w, w, out.data_ptr(),
+                                                              cap, ctypes.byref(n)))
+        return out[: n.value]
+
+    def _plane(self, img, edge):
+        e = 2 if edge else 0
+        return img.shape[0] + e, img.shape[1] + e
+
+    def segment(self, img, seeds, max_level=254, edge=False, engine=None, out=None):
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        assert seeds.dtype == torch.int32 and seeds.is_cuda and (seeds.numel() == 0 or seeds.is_contiguous())
+        h, w = img.shape
+        if out is None:
+            out = torch.empty(self._plane(img, edge), dtype=torch.int32, device=self.device)
+        opt = self.options(max_level, edge, engine)
+        ns = seeds.shape[0] if seeds.dim() == 2 else 0
+        self.ctx.check(_ffi.lib().ws_segment_device(self.ctx.handle, img.data_ptr(), h, w, w,
+                                                    seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),
+                                                    out.data_ptr()))
+        return out
+
+    def merge(self, img, seeds, max_level=254, edge=False, out=None):
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        h, w = img.shape
+        if out is None:
+            out = torch.empty(self._plane(img, edge), dtype=torch.int32, device=self.device)
+        opt = self.options(max_level, edge)
+        ns = seeds.shape[0] if seeds.dim() == 2 else 0
+        self.ctx.check(_ffi.lib().ws_merge_device(self.ctx.handle, img.data_ptr(), h, w, w,
+                                                  seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),
+                                                  out.data_ptr()))
+        return out
+
+    def last_arrival(self):
+        """Arrival stamps (level << 24 | ring) of the last fused-engine call, as a tensor copy."""
+        p = ctypes.c_void_p()
+        h = ctypes.c_size_t()
+        w = ctypes.c_size_t()
+        self.ctx.check(_ffi.lib().ws_last_arrival_device(self.ctx.handle, ctypes.byref(p), ctypes.byref(h), ctypes.byref(w)))
+        out = torch.empty((h.value, w.value), dtype=torch.int32, device=self.device)
+        self.ctx.check(_ffi.lib().ws_copy_last_arrival_device(self.ctx.handle, out.data_ptr(), out.numel()))
+        return out
+
+    def stats(self):
+        return self.ctx.stats()

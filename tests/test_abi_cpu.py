@@ -1,0 +1,108 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/ws_hip.h declares, the host-side mirror reproduces the reference's builder behaviour,
+and the product fails loudly (no fallback) when there is no HIP device."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_unit_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    ge.build_hip()
+    return ge.load_package()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ws_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(ws_[a-z0-9_]+)\s*\(", text))
+    names -= {"ws_level_cb"}
+    return names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    assert declared == set(pkg._ffi.SIGNATURES), declared ^ set(pkg._ffi.SIGNATURES)
+    raw = ctypes.CDLL(pkg._ffi.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert pkg._ffi.lib().ws_abi_version() == 1
+
+
+def test_options_default_and_validation(pkg):
+    L = pkg._ffi.lib()
+    opt = pkg._ffi.Options()
+    assert L.ws_options_default(ctypes.byref(opt)) == 0
+    b = GOLD["builder"]
+    assert opt.max_water_level == b["default_max_water_level"] and opt.edge_correction == 0
+    for v in b["valid"]:
+        opt.max_water_level = v
+        assert L.ws_options_validate(ctypes.byref(opt)) == 0
+    for v in b["max_to_high"]:
+        opt.max_water_level = v
+        assert L.ws_options_validate(ctypes.byref(opt)) == pkg._ffi.WS_ERR_MAX_TOO_HIGH
+    for v in b["max_to_low"]:
+        opt.max_water_level = v
+        assert L.ws_options_validate(ctypes.byref(opt)) == pkg._ffi.WS_ERR_MAX_TOO_LOW
+    assert b"254" in L.ws_strerror(pkg._ffi.WS_ERR_MAX_TOO_HIGH)
+
+
+def test_builder_mirrors_reference(pkg):
+    # lib.rs:936-946 defaults; lib.rs:1026-1030 validation, for both build_* methods
+    b = pkg.TransformBuilder.default()
+    assert b.max_water_level == 254 and b.edge_correction is False and b.wlvl_hook is None
+    for build in ("build_segmenting", "build_merging"):
+        with pytest.raises(pkg.MaxToHigh):
+            getattr(pkg.TransformBuilder.new().set_max_water_lvl(255), build)()
+        with pytest.raises(pkg.MaxToLow):
+            getattr(pkg.TransformBuilder.new().set_max_water_lvl(0), build)()
+        ws = getattr(pkg.TransformBuilder.new().set_max_water_lvl(127).enable_edge_correction(), build)()
+        assert ws.max_water_level == 127 and ws.edge_correction is True
+    assert issubclass(pkg.MaxToHigh, pkg.BuildErr) and issubclass(pkg.MaxToLow, pkg.BuildErr)
+    assert (pkg.UNCOLOURED, pkg.NORMAL_MAX, pkg.ALWAYS_FILL, pkg.NEVER_FILL) == (0, 254, 0, 255)
+
+
+def test_merge_transform_stub_matches_reference_stub(pkg):
+    # lib.rs:1524-1536: zeros with the interior set to 123, seeds ignored (pure host code)
+    ws = pkg.TransformBuilder.default().build_merging()
+    out = ws.transform(np.zeros((5, 7), np.uint8), [(1, 1)])
+    assert out.dtype == np.uint64 and (out[1:-1, 1:-1] == 123).all()
+    assert out[0].sum() == 0 and out[-1].sum() == 0 and out[:, 0].sum() == 0 and out[:, -1].sum() == 0
+
+
+def test_no_device_fails_loudly(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert pkg._ffi.lib().ws_ctx_create(0, ctypes.byref(h)) == pkg._ffi.WS_ERR_NO_DEVICE
+    with pytest.raises(pkg.WatershedError):
+        pkg.TransformBuilder.default().build_segmenting().transform(np.zeros((8, 8), np.uint8), [(3, 3)])
+
+
+def test_missing_library_raises(pkg, monkeypatch):
+    ffi = pkg._ffi
+    monkeypatch.setattr(ffi, "_lib", None)
+    monkeypatch.setattr(ffi, "LIB_PATH", ffi.LIB_PATH + ".absent")
+    with pytest.raises(ImportError):
+        ffi.lib()
+
+
+def test_product_does_not_reference_the_oracle():
+    # the shipped package must never import, load or call anything under oracle/
+    pkg_dir = os.path.join(ROOT, "rustronomy-watershed_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
