@@ -43,6 +43,7 @@ struct ws_ctx {
   ws_stats stats{};
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
+  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes;
   uint32_t *pinned = nullptr;      // COUNTER_RING + 4 words of pinned host memory
   hipEvent_t ring_ev[COUNTER_RING]{};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -54,7 +55,6 @@ struct ws_ctx {
   std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
-  ws_merge_state merge;
 };
 
 namespace {
@@ -456,9 +456,9 @@ void ws_ctx_destroy(ws_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux})
+  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux,
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes})
     if (b->p) (void)hipFree(b->p);
-  ws_merge_state_free(&c->merge);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < COUNTER_RING; ++i) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
@@ -617,24 +617,214 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out) {
 
 // ---- merging (ws_merge.hip) ------------------------------------------------------------------
 
+}  // extern "C"
+
+namespace {
+
+// mflags layout (u64 words): per-level histograms / cursors, lake cursor, per-level lake offsets
+constexpr int MF_HIST_PX = 0;
+constexpr int MF_HIST_ED = NLEVELS;
+constexpr int MF_CUR_PX = 2 * NLEVELS;
+constexpr int MF_CUR_ED = 3 * NLEVELS;
+constexpr int MF_LAKE_CURSOR = 4 * NLEVELS;
+constexpr int MF_LAKE_OFFSETS = 4 * NLEVELS + 8;          // NLEVELS + 1 entries
+constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // u32 counter lives in this word
+constexpr int MF_WORDS = 5 * NLEVELS + 24;
+
+struct LevelBuckets {
+  std::vector<uint64_t> off_px, off_ed;    // NLEVELS + 1 prefix sums
+};
+
+// Segmenting result (stamps + colours) -> per-level buckets of arriving pixels and crossing edges.
+int build_buckets(ws_ctx *c, const uint32_t *keys, const uint32_t *seg_labels, int ph, int pw, LevelBuckets *lb) {
+  int rc;
+  if ((rc = ensure(c, c->mflags, MF_WORDS * sizeof(uint64_t)))) return rc;
+  u64c *mf = (u64c *)c->mflags.p;
+  HIP_TRY(c, hipMemsetAsync(mf, 0, MF_WORDS * sizeof(uint64_t), c->stream));
+  HIP_TRY(c, level_hist(c->stream, keys, seg_labels, ph, pw, mf + MF_HIST_PX, mf + MF_HIST_ED));
+  std::vector<uint64_t> hist(2 * NLEVELS);
+  HIP_TRY(c, hipMemcpyAsync(hist.data(), mf, 2 * NLEVELS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  lb->off_px.assign(NLEVELS + 1, 0);
+  lb->off_ed.assign(NLEVELS + 1, 0);
+  for (int l = 0; l < NLEVELS; ++l) {
+    lb->off_px[l + 1] = lb->off_px[l] + hist[MF_HIST_PX + l];
+    lb->off_ed[l + 1] = lb->off_ed[l] + hist[MF_HIST_ED + l];
+  }
+  const size_t npx = lb->off_px[NLEVELS], ned = lb->off_ed[NLEVELS];
+  if ((rc = ensure(c, c->px_items, (npx ? npx : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->edge_items, (ned ? ned : 1) * sizeof(uint2)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(mf + MF_CUR_PX, lb->off_px.data(), NLEVELS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(mf + MF_CUR_ED, lb->off_ed.data(), NLEVELS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, level_scatter(c->stream, keys, seg_labels, ph, pw, mf + MF_CUR_PX, mf + MF_CUR_ED,
+                           (uint32_t *)c->px_items.p, (uint2 *)c->edge_items.p));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));      // off_* vectors were the copy sources
+  return WS_OK;
+}
+
+int ensure_uf(ws_ctx *c, size_t n_colours) {
+  int rc;
+  if ((rc = ensure(c, c->uf_parent, n_colours * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->uf_size, n_colours * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->uf_hooked, n_colours * sizeof(uint32_t)))) return rc;
+  HIP_TRY(c, uf_init(c->stream, (uint32_t *)c->uf_parent.p, (uint32_t *)c->uf_size.p, n_colours));
+  return WS_OK;
+}
+
+// Per-level driver shared by the merging hook and both transform_to_list flavours.
+//   merging: union this level's crossing edges (lib.rs:1449-1466 in closed form)
+//   want_sizes: keep per-lake areas (lib.rs:628-635)
+//   per_level(l): called after level l is complete (device state current on c->stream)
+template <class F>
+int level_loop(ws_ctx *c, const LevelBuckets &lb, uint32_t max_level, bool merging, bool want_sizes, F per_level) {
+  uint32_t *parent = (uint32_t *)c->uf_parent.p, *size = (uint32_t *)c->uf_size.p, *hooked = (uint32_t *)c->uf_hooked.p;
+  u64c *mf = (u64c *)c->mflags.p;
+  uint32_t *hooked_count = (uint32_t *)(mf + MF_HOOKED);
+  const uint32_t *px_items = (const uint32_t *)c->px_items.p;
+  const uint2 *edge_items = (const uint2 *)c->edge_items.p;
+  for (uint32_t l = 0; l <= max_level; ++l) {
+    const size_t e0 = lb.off_ed[l], e1 = lb.off_ed[l + 1], p0 = lb.off_px[l], p1 = lb.off_px[l + 1];
+    if (merging && e1 > e0) {
+      HIP_TRY(c, hipMemsetAsync(hooked_count, 0, sizeof(uint32_t), c->stream));
+      HIP_TRY(c, union_edges(c->stream, edge_items + e0, e1 - e0, parent, want_sizes ? hooked : nullptr, hooked_count));
+      if (want_sizes) HIP_TRY(c, fold_sizes(c->stream, hooked, hooked_count, parent, size));
+      c->stats.merge_levels++;
+    }
+    if (want_sizes && p1 > p0) HIP_TRY(c, add_arrivals(c->stream, px_items + p0, p1 - p0, parent, size));
+    int rc = per_level(l);
+    if (rc) return rc;
+  }
+  return WS_OK;
+}
+
+int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+               size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels,
+               ws_lake *lakes, size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+  if (!c) return WS_ERR_BAD_ARG;
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = ph * pw;
+  const bool want_list = n_lakes != nullptr;
+  const uint8_t *d_img;
+  size_t d_stride;
+  const uint32_t *d_seeds;
+  if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
+  stats_begin(c);
+  if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
+  uint32_t *seg = (uint32_t *)c->labels.p;
+  uint64_t *d_out64 = (uint64_t *)c->out64.p;
+  // the flood itself is the segmenting one (same coloured set, same arrival stamps: lib.rs:1394-1438 == 1704-1748)
+  if ((rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, seg))) return rc;
+  const uint32_t *keys = (const uint32_t *)c->keys.p;
+  uint32_t *parent;
+  LevelBuckets lb;
+  if (n) {
+    if ((rc = build_buckets(c, keys, seg, (int)ph, (int)pw, &lb))) return rc;
+  } else {
+    lb.off_px.assign(NLEVELS + 1, 0);
+    lb.off_ed.assign(NLEVELS + 1, 0);
+  }
+  if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
+  parent = (uint32_t *)c->uf_parent.p;
+  u64c *mf = (u64c *)c->mflags.p;
+  if (want_list) {
+    if ((rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(c, c->mflags, MF_WORDS * sizeof(uint64_t)))) return rc;
+    mf = (u64c *)c->mflags.p;
+    HIP_TRY(c, hipMemsetAsync(mf + MF_LAKE_CURSOR, 0, (NLEVELS + 9) * sizeof(uint64_t), c->stream));
+  }
+  const uint8_t *himg = cb ? hook_image(c, img, h, w, stride, opt->edge_correction) : nullptr;
+  if (cb) c->host64.resize(n ? n : 1);
+
+  rc = level_loop(c, lb, opt->max_water_level, merging, want_list, [&](uint32_t l) -> int {
+    if (want_list) {
+      // offsets[l] = lake cursor before this level's records
+      HIP_TRY(c, hipMemcpyAsync(mf + MF_LAKE_OFFSETS + l, mf + MF_LAKE_CURSOR, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_CURSOR));
+    }
+    if (cb) {
+      if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
+      else HIP_TRY(c, snapshot_level(c->stream, keys, seg, d_out64, n, l));
+      HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      cb(user, (uint8_t)l, opt->max_water_level, himg, c->host64.data(), ph, pw);        // lib.rs:1510-1518
+    }
+    return WS_OK;
+  });
+  if (rc) return rc;
+
+  if (want_list) {
+    const uint32_t levels = (uint32_t)opt->max_water_level + 1;
+    HIP_TRY(c, hipMemcpyAsync(mf + MF_LAKE_OFFSETS + levels, mf + MF_LAKE_CURSOR, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(offsets, mf + MF_LAKE_OFFSETS, (levels + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_lakes = offsets[levels];
+    const size_t got = std::min<size_t>(*n_lakes, cap);
+    if (got) HIP_TRY(c, hipMemcpyAsync(lakes, c->lakes.p, got * sizeof(ws_lake), hipMemcpyDeviceToHost, c->stream));
+    for (uint32_t l = 0; l < levels; ++l) uncoloured[l] = n - lb.off_px[l + 1];                // index 0 of lib.rs:630's vector
+  }
+  if (out_labels && n) {
+    if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, opt->max_water_level));
+    else HIP_TRY(c, widen_labels(c->stream, seg, d_out64, n));
+    HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  rc = stats_end(c);
+  if (rc) return rc;
+  if (want_list && *n_lakes > cap) return fail(c, WS_ERR_CAPACITY, "lake buffer too small");
+  return WS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Final canonical labels only: one union pass over the whole image, no level buckets.
 int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
                     size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
-  (void)d_img; (void)h; (void)w; (void)stride; (void)d_seeds_rc; (void)n_seeds; (void)opt; (void)d_labels;
-  return fail(c, WS_ERR_UNSUPPORTED, "merging transform: not built yet");
+  if (!c) return WS_ERR_BAD_ARG;
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  if ((!d_img && h * w) || (!d_seeds_rc && n_seeds) || (!d_labels && ph * pw)) return fail(c, WS_ERR_BAD_ARG, "null device pointer");
+  if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = ph * pw;
+  if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  stats_begin(c);
+  const uint8_t *src = d_img;
+  size_t src_stride = stride;
+  if (opt->edge_correction) {
+    if ((rc = ensure(c, c->img, ph * pw))) return rc;
+    HIP_TRY(c, pad_image(c->stream, d_img, stride, (int)h, (int)w, (uint8_t *)c->img.p));
+    src = (const uint8_t *)c->img.p;
+    src_stride = pw;
+  }
+  uint32_t *seg = (uint32_t *)c->labels.p;
+  if ((rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, seg))) return rc;
+  if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
+  {
+    Span sp(c, KC_OTHER);
+    HIP_TRY(c, union_image(c->stream, (const uint32_t *)c->keys.p, seg, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p));
+    HIP_TRY(c, relabel_u32(c->stream, (const uint32_t *)c->keys.p, seg, (uint32_t *)c->uf_parent.p, d_labels, n, opt->max_water_level));
+  }
+  c->stats.merge_levels = 1;
+  return stats_end(c);
 }
 
 int ws_merge_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                        size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
-  (void)img; (void)h; (void)w; (void)stride; (void)seeds_rc; (void)n_seeds; (void)opt; (void)cb; (void)user; (void)out_labels;
-  return fail(c, WS_ERR_UNSUPPORTED, "merging transform: not built yet");
+  return merge_host(c, true, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels, nullptr, 0, nullptr, nullptr, nullptr);
 }
 
 int ws_transform_to_list(ws_ctx *c, int merging, const uint8_t *img, size_t h, size_t w, size_t stride,
                          const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *lakes, size_t cap,
                          size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
-  (void)merging; (void)img; (void)h; (void)w; (void)stride; (void)seeds_rc; (void)n_seeds; (void)opt; (void)lakes; (void)cap;
-  (void)n_lakes; (void)offsets; (void)uncoloured;
-  return fail(c, WS_ERR_UNSUPPORTED, "transform_to_list: not built yet");
+  if (!n_lakes || !offsets || !uncoloured || (!lakes && cap)) return fail(c, WS_ERR_BAD_ARG, "null output pointer");
+  return merge_host(c, merging != 0, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, nullptr, lakes, cap, n_lakes,
+                    offsets, uncoloured);
 }
 
 }  // extern "C"

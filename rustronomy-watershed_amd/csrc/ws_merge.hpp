@@ -1,11 +1,53 @@
-// ws_merge.hpp -- state of the merging transform (filled in by ws_merge.hip).
+// ws_merge.hpp -- launch wrappers of the merging-transform kernels (ws_merge.hip).
+//
+// The reference's merging driver (lib.rs:1328-1522) floods exactly like the segmenting one
+// and, after every level, merges every pair of touching lakes (find_merge lib.rs:393-445,
+// make_colour_map 467-542, recolour 589-592).  Because a flooded pixel always takes the
+// colour of an already coloured neighbour, the lakes after level l are the connected
+// components of the pixels coloured by level l, and -- expressed over the SEGMENTING
+// result -- the classes of a union-find over seed colours joined by every adjacent pixel
+// pair (p, q) with different segmenting colours and max(level(p), level(q)) <= l, where
+// at least one of p, q is interior (find_merge only looks at 3x3 window centres).
+// The canonical lake id is the smallest colour of the class = the union-by-min root.
 #pragma once
+
+#include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
-struct ws_merge_state {
-  void *parent = nullptr;   // device union-find forest over pixels
-  size_t cap = 0;
-};
+namespace wsk {
 
-inline void ws_merge_state_free(ws_merge_state *) {}
+constexpr int NLEVELS = 256;
+
+typedef unsigned long long u64c;
+
+// parent[i] = i for i in 0..n, size[i] = 0
+hipError_t uf_init(hipStream_t s, uint32_t *parent, uint32_t *size, size_t n);
+
+// per-level histograms of arriving pixels and of label-crossing edges (256 bins each)
+hipError_t level_hist(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
+                      u64c *hist_px, u64c *hist_edge);
+// bucketed scatter: px_items[cursor_px[lvl]++] = colour, edge_items[cursor_edge[lvl]++] = (a,b)
+hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
+                         u64c *cursor_px, u64c *cursor_edge, uint32_t *px_items, uint2 *edge_items);
+
+// lock-free union-by-min of n edges; every node that loses its root status is appended to hooked
+hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *parent, uint32_t *hooked,
+                       uint32_t *hooked_count);
+hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, uint32_t *parent,
+                      uint32_t *size);
+hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size);
+// appends (colour, area) of every root with area > 0 at lakes[*cursor ...); counts past cap too
+hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
+                      uint64_t *lakes, size_t cap, u64c *cursor);
+
+// final-only path: union every crossing edge of the whole image in one launch
+hipError_t union_image(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
+                       uint32_t *parent);
+// out[p] = coloured by `level` ? root(labels[p]) : 0
+hipError_t relabel_u32(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint32_t *parent,
+                       uint32_t *out, size_t n, uint32_t level);
+hipError_t relabel_u64(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint32_t *parent,
+                       uint64_t *out, size_t n, uint32_t level);
+
+}  // namespace wsk

@@ -1,0 +1,183 @@
+"""Parity of the merging transform and of transform_to_list with the CPU oracle (-m gpu).
+
+The reference's merged-lake ids are arbitrary (sort/dedup order, lib.rs:440-443, 508-541), so
+planes are compared after canonicalisation (smallest seed colour in the lake) and lake-size
+lists as sorted multisets."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import cases
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    ge.build_hip()
+    return ge.load_package()
+
+
+def _merging(pkg, max_level=254, edge=False, hook=None):
+    b = pkg.TransformBuilder.new().set_max_water_lvl(max_level)
+    if edge:
+        b.enable_edge_correction()
+    if hook is not None:
+        b.set_wlvl_hook(hook)
+    return b.build_merging()
+
+
+def _oracle_levels(img, seeds, **kw):
+    snaps = []
+    ol.merge(img, seeds, hook=lambda l, m, i, c: snaps.append(ol.canonicalise(c, seeds)[0]), **kw)
+    return snaps
+
+
+@pytest.mark.parametrize("shape,seed,edge", [((24, 24), 1, False), ((50, 70), 2, False), ((96, 96), 3, True),
+                                              ((130, 67), 4, False), ((200, 300), 5, True)])
+def test_merge_history_matches_oracle_every_level(pkg, shape, seed, edge):
+    img = cases.field(*shape, seed)
+    seeds = ol.find_local_minima(img)
+    want = _oracle_levels(img, seeds, edge=edge)
+    hist = _merging(pkg, edge=edge).transform_history(img, seeds)
+    assert [l for l, _ in hist] == list(range(255))
+    for (lvl, got), w in zip(hist, want):
+        assert got.shape == w.shape
+        assert (got == w).all(), lvl
+
+
+def test_merge_partition_matches_randomised_faithful_reference_shape(pkg):
+    # the oracle run with the reference's own random tie-break and its order-dependent
+    # representatives must give the same partition and the same sorted lake sizes
+    img = cases.field(80, 90, 7)
+    seeds = ol.find_local_minima(img)
+    snaps = []
+    ol.merge(img, seeds, tie=ol.TIE_RANDOM, rng_seed=11, mode=ol.MAP_FAITHFUL, hook=lambda l, m, i, c: snaps.append(c.copy()))
+    hist = _merging(pkg).transform_history(img, seeds)
+    for lvl in range(0, 255, 5):
+        got = hist[lvl][1]
+        assert (ol.canonicalise(snaps[lvl], seeds)[0] == got).all(), lvl
+        assert sorted(ol.find_lake_sizes(snaps[lvl])[1:].tolist()) == sorted(ol.find_lake_sizes(got)[1:].tolist())
+
+
+def test_merge_adversarial_cases(pkg):
+    for name, img, seeds in cases.adversarial_cases():
+        seeds = cases.seeds_or_maxima(img, seeds)
+        if img.size == 0:
+            continue
+        for edge in (False, True):
+            want = _oracle_levels(img, seeds, edge=edge)
+            hist = _merging(pkg, edge=edge).transform_history(img, seeds)
+            for lvl in (0, 1, 7, 9, 100, 254):
+                assert (hist[lvl][1] == want[lvl]).all(), (name, edge, lvl)
+
+
+@pytest.mark.parametrize("maxlvl", [1, 60, 254])
+def test_merge_to_list_matches_oracle_lake_sizes(pkg, maxlvl):
+    img = cases.field(72, 88, 9)
+    seeds = ol.find_local_minima(img)
+    want = []
+    ol.merge(img, seeds, max_level=maxlvl, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(ol.canonicalise(c, seeds)[0])))
+    got = _merging(pkg, max_level=maxlvl).transform_to_list(img, seeds)
+    assert [l for l, _ in got] == list(range(maxlvl + 1))
+    for (lvl, hist), w in zip(got, want):
+        assert hist.shape == w.shape == (72 * 88 + 1,)              # lib.rs:630: pixels + 1
+        assert (hist == w).all(), lvl
+
+
+def test_segmenting_to_list_matches_oracle(pkg):
+    img = cases.field(64, 80, 10)
+    seeds = ol.find_local_minima(img)
+    want = []
+    ol.segment(img, seeds, max_level=90, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(c)))
+    ws = pkg.TransformBuilder.new().set_max_water_lvl(90).build_segmenting()
+    got = ws.transform_to_list(img, seeds)
+    for (lvl, hist), w in zip(got, want):
+        assert (hist == w).all(), lvl
+
+
+def test_merge_to_list_sparse_core_bench_shape(pkg):
+    # tests/core_bench.rs:27-61: merging transform_to_list on a 1024x1024 Uniform(0,254) field
+    img = cases.field(1024, 1024, 1)
+    ws = _merging(pkg)
+    seeds = ws.find_local_minima(img)
+    res = ws.transform_to_list_sparse(img, seeds)
+    assert len(res) == 255
+    interior = 1022 * 1022
+    # conservation: areas + uncoloured = pixels, at every level; lakes only ever merge
+    prev_lakes = None
+    for lvl, unc, colours, areas in res:
+        assert int(areas.sum()) + unc == 1024 * 1024
+        assert len(set(colours.tolist())) == len(colours)
+        if prev_lakes is not None:
+            assert len(colours) <= prev_lakes
+        prev_lakes = len(colours)
+    assert res[-1][1] == 1024 * 1024 - interior                     # only the border stays uncoloured
+    # spot-check three levels against the arrival-form oracle (canonical partition per level)
+    want = {}
+    ol.merge_arrival(img, seeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)) if l in (3, 120, 254) else None)
+    for lvl in (3, 120, 254):
+        _, unc, colours, areas = res[lvl]
+        dense = np.zeros(1024 * 1024 + 1, np.uint64)
+        dense[colours.astype(np.int64)] = areas
+        dense[0] = unc
+        assert (dense == want[lvl]).all(), lvl
+
+
+def test_merge_final_labels_device_and_host(pkg):
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    img = eng.random_field(600, 700, 4)
+    seeds = eng.find_local_minima(img)
+    got = eng.merge(img, seeds, max_level=100)
+    torch.cuda.synchronize()
+    himg = img.cpu().numpy()
+    hseeds = seeds.cpu().numpy().astype(np.uint64)
+    want = ol.merge_arrival(himg, hseeds, max_level=100)
+    assert (got.cpu().numpy().view(np.uint32) == want).all()
+    host = _merging(pkg, max_level=100).transform_final(himg, hseeds)
+    assert (host == want).all()
+
+
+def test_merge_config3_8192_properties(pkg):
+    # BASELINE config C3: 8192x8192 merging.  The oracle cannot run this size; check the defining
+    # properties on the device: the merged plane is constant on every segmenting lake, two adjacent
+    # coloured pixels (one of them interior) always share a merged id, and ids are the smallest
+    # colour of their class.
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    size = 8192
+    img = eng.random_field(size, size, 1)
+    seeds = eng.find_local_minima(img)
+    seg = eng.segment(img, seeds)
+    mer = eng.merge(img, seeds)
+    torch.cuda.synchronize()
+    seg64 = seg.to(torch.int64) & 0xFFFFFFFF
+    mer64 = mer.to(torch.int64) & 0xFFFFFFFF
+    assert bool(((seg64 == 0) == (mer64 == 0)).all())
+    assert bool((mer64 <= seg64).all())                       # canonical id = smallest colour of the class
+    # constant on segmenting lakes: map colour -> merged id must be a function
+    S = seeds.shape[0]
+    lo = torch.full((S + 1,), 1 << 40, dtype=torch.int64, device=img.device)
+    hi = torch.zeros((S + 1,), dtype=torch.int64, device=img.device)
+    lo.scatter_reduce_(0, seg64.flatten(), mer64.flatten(), reduce="amin")
+    hi.scatter_reduce_(0, seg64.flatten(), mer64.flatten(), reduce="amax")
+    used = hi > 0
+    assert bool((lo[used] == hi[used]).all())
+    # adjacency closure (interior-centre rule of find_merge, lib.rs:411-434)
+    inter = torch.zeros((size, size), dtype=torch.bool, device=img.device)
+    inter[1:-1, 1:-1] = True
+    a, b = mer64[:, :-1], mer64[:, 1:]
+    ok = (a == 0) | (b == 0) | (a == b) | ~(inter[:, :-1] | inter[:, 1:])
+    assert bool(ok.all())
+    a, b = mer64[:-1, :], mer64[1:, :]
+    ok = (a == 0) | (b == 0) | (a == b) | ~(inter[:-1, :] | inter[1:, :])
+    assert bool(ok.all())
+    # on a uniform random field the whole interior ends up as one lake with id 1... unless a border seed
+    ids = torch.unique(mer64[1:-1, 1:-1])
+    assert ids.numel() == 1
