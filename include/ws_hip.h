@@ -206,6 +206,22 @@ int ws_last_arrival_device(ws_ctx *ctx, const uint32_t **d_keys, size_t *h, size
 /* Copies those stamps into the caller's device buffer of n_elems >= h*w words (stream ordered). */
 int ws_copy_last_arrival_device(ws_ctx *ctx, uint32_t *d_dst, size_t n_elems);
 
+/* ---- one field tiled over several GPUs: row blocks with halo rows ----------------------
+ *
+ * A rank holds its rows of the global field plus one extra (halo) row on every side that has a
+ * neighbour.  The local plane's first and last rows are then either the global border or a halo,
+ * which the flood never writes (lib.rs:220-222), so a block is relaxed exactly like a whole
+ * image.  The caller alternates: ws_block_relax on every rank -> exchange halo rows of d_keys
+ * (RCCL send/recv) -> all-reduce of `changed`, until no rank changed; then the same loop with
+ * ws_block_resolve and d_labels.  Seeds carry GLOBAL colours (index in the caller's slice + 1,
+ * lib.rs:1670-1672) and LOCAL coordinates; every rank paints the seeds that fall on any of its
+ * local rows, halo rows included.  rustronomy-watershed_amd/distributed.py drives this. */
+int ws_block_init(ws_ctx *ctx, size_t h, size_t w, const uint32_t *d_seeds_rc, const uint32_t *d_colours,
+                  size_t n_seeds, uint32_t *d_keys, uint32_t *d_labels);
+int ws_block_relax(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                   uint8_t max_water_level, uint32_t *d_keys, int *changed);
+int ws_block_resolve(ws_ctx *ctx, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w, int *changed);
+
 /* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
 int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                            uint64_t seed);

@@ -81,6 +81,9 @@ SIGNATURES = {
     "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_last_arrival_device": (ctypes.c_int, [vp, ctypes.POINTER(vp), szp, szp]),
     "ws_copy_last_arrival_device": (ctypes.c_int, [vp, vp, sz]),
+    "ws_block_init": (ctypes.c_int, [vp, sz, sz, vp, vp, sz, vp, vp]),
+    "ws_block_relax": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint8, vp, ctypes.POINTER(ctypes.c_int)]),
+    "ws_block_resolve": (ctypes.c_int, [vp, vp, vp, sz, sz, ctypes.POINTER(ctypes.c_int)]),
     "ws_random_field_device": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint64]),
 }
 

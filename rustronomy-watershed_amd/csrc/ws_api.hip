@@ -66,6 +66,7 @@ constexpr int FLAG_SEED_ERR = COUNTER_RING + 1;  // 1
 constexpr int FLAG_TILES_RELAX = COUNTER_RING + 2;
 constexpr int FLAG_TILES_RESOLVE = COUNTER_RING + 3;
 constexpr int FLAG_TOTAL = COUNTER_RING + 4;     // minima total
+constexpr int FLAG_ANY_CHANGE = COUNTER_RING + 5;
 constexpr int FLAG_WORDS = COUNTER_RING + 8;
 
 int fail(ws_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -204,14 +205,14 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
     HIP_TRY(c, fill_u32(c->stream, keys, n, KEY_INF));
     HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 4 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, n_seeds, ph, pw, d_labels, keys, flags + FLAG_SEED_ERR));
+    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, keys, flags + FLAG_SEED_ERR));
   }
   if (n == 0) return WS_OK;
 
   rc = pass_loop(c, flags, ntiles, &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps,
-                      flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX);
+                      flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
   });
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
@@ -225,7 +226,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
     Span sp(c, KC_RESOLVE);
     return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, flags + FLAG_COUNTERS,
-                        flags + FLAG_TILES_RESOLVE);
+                        flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
   });
   if (rc) return rc;
   c->stats.launches_resolve = c->stats.resolve_passes;
@@ -255,7 +256,7 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   c->have_keys = false;
   HIP_TRY(c, hipMemsetAsync(cur, 0, n * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, scatter_seeds(c->stream, d_seeds, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
+  HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -612,6 +613,82 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out) {
   if (h < 2 || w < 2) return WS_OK;
   for (size_t r = 1; r + 1 < h; ++r)
     for (size_t col = 1; col + 1 < w; ++col) out[r * w + col] = 123;   // lib.rs:1532
+  return WS_OK;
+}
+
+// ---- row blocks of one larger field (multi-GPU tiling) -----------------------------------------
+//
+// A rank owns a block of rows of the global field and holds it with one extra row on every side
+// that has a neighbour rank.  First/last local rows are therefore either the global border or a
+// halo copy, i.e. exactly the rows the flood never writes (lib.rs:220-222), so the single-GPU
+// kernels run unchanged on the local plane; the caller exchanges halo rows between calls.
+
+int ws_block_init(ws_ctx *c, size_t h, size_t w, const uint32_t *d_seeds_rc, const uint32_t *d_colours, size_t n_seeds,
+                  uint32_t *d_keys, uint32_t *d_labels) {
+  if (!c || (h * w && (!d_keys || !d_labels)) || (n_seeds && (!d_seeds_rc || !d_colours))) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t *flags = (uint32_t *)c->flags.p;
+  const size_t n = h * w;
+  HIP_TRY(c, fill_u32(c->stream, d_keys, n, KEY_INF));
+  if (n) HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 4 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, scatter_seeds(c->stream, d_seeds_rc, d_colours, n_seeds, (int)h, (int)w, d_labels, d_keys, flags + FLAG_SEED_ERR));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the local plane");
+  return WS_OK;
+}
+
+int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, uint8_t max_water_level,
+                   uint32_t *d_keys, int *changed) {
+  if (!c || !changed || (h * w && (!d_img || !d_keys)) || stride < w) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
+  *changed = 0;
+  if (h * w == 0) return WS_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t ntiles = (size_t)tiles_of((int)w) * tiles_of((int)h);
+  int rc;
+  if ((rc = ensure(c, c->stamps, ntiles * 4 * 2 * sizeof(uint32_t)))) return rc;
+  uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY_CHANGE, 0, sizeof(uint32_t), c->stream));
+  uint32_t passes = 0;
+  rc = pass_loop(c, flags, ntiles, &passes, [&](uint32_t pass) {
+    return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, flags + FLAG_COUNTERS,
+                      flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
+  });
+  if (rc) return rc;
+  c->stats.relax_passes += passes;
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY_CHANGE], flags + FLAG_ANY_CHANGE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pinned[COUNTER_RING]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+  *changed = c->pinned[FLAG_ANY_CHANGE] != 0;
+  return WS_OK;
+}
+
+int ws_block_resolve(ws_ctx *c, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w, int *changed) {
+  if (!c || !changed || (h * w && (!d_keys || !d_labels))) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
+  *changed = 0;
+  if (h * w == 0) return WS_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t ntiles = (size_t)tiles_of((int)w) * tiles_of((int)h);
+  int rc;
+  if ((rc = ensure(c, c->stamps, ntiles * 4 * 2 * sizeof(uint32_t)))) return rc;
+  uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY_CHANGE, 0, sizeof(uint32_t), c->stream));
+  uint32_t passes = 0;
+  rc = pass_loop(c, flags, ntiles, &passes, [&](uint32_t pass) {
+    return resolve_pass(c->stream, d_keys, d_labels, (int)h, (int)w, pass, stamps, flags + FLAG_COUNTERS,
+                        flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
+  });
+  if (rc) return rc;
+  c->stats.resolve_passes += passes;
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY_CHANGE], flags + FLAG_ANY_CHANGE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *changed = c->pinned[FLAG_ANY_CHANGE] != 0;
   return WS_OK;
 }
 

@@ -34,7 +34,7 @@ struct Launch {
 hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst);
 hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
-hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw,
+hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag);
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
@@ -42,9 +42,9 @@ hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *l
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
                       int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run);
+                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change);
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run);
+                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change);
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

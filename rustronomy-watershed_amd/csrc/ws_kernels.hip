@@ -67,7 +67,7 @@ hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w
 
 // lib.rs:1670-1677: colour i+1 at seed i; a later duplicate overwrites an earlier one
 // (atomicMax keeps the largest index = the last writer of the sequential loop).
-__global__ void k_scatter_seeds(const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
+__global__ void k_scatter_seeds(const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw, uint32_t *labels,
                                 uint32_t *keys, uint32_t *err_flag) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -75,16 +75,16 @@ __global__ void k_scatter_seeds(const uint32_t *seeds_rc, size_t n, int ph, int 
     const uint32_t r = seeds_rc[2 * i], c = seeds_rc[2 * i + 1];
     if (r >= (uint32_t)ph || c >= (uint32_t)pw) { atomicExch(err_flag, 1u); continue; }
     const size_t p = (size_t)r * pw + c;
-    atomicMax(&labels[p], (uint32_t)(i + 1));
+    atomicMax(&labels[p], colours ? colours[i] : (uint32_t)(i + 1));
     if (keys) keys[p] = 0u;
   }
 }
 
-hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw,
+hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n, ph, pw, labels, keys, err_flag);
+  k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, keys, err_flag);
   return hipGetLastError();
 }
 
@@ -152,7 +152,7 @@ __device__ __forceinline__ bool tile_must_run(const uint32_t *stamps_prev, int t
 __global__ __launch_bounds__(NTHREADS) void k_relax(const uint8_t *__restrict__ img, size_t img_stride,
                                                     uint32_t *keys, int H, int W, int tilesX, int tilesY,
                                                     uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                                                    uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run) {
+                                                    uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change) {
   __shared__ uint32_t sT[LP][LP];
   __shared__ uint32_t s_edges;
 
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void k_relax(const uint8_t *__restrict__ 
   if (strip == (NTHREADS / 64) - 1 && (changed_mask >> (STRIP - 1))) e |= 2u;  // bottom row
   if (lane == 0 && changed_mask) e |= 4u;                                 // left column
   if (lane == 63 && changed_mask) e |= 8u;                                // right column
+  if (changed_mask) e |= 16u;                                             // anything at all
   if (e) atomicOr(&s_edges, e);
   __syncthreads();
   if (tid == 0) {
@@ -253,17 +254,18 @@ __global__ __launch_bounds__(NTHREADS) void k_relax(const uint8_t *__restrict__ 
       if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
       if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
       if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
-      atomicAdd(&counters[pass % COUNTER_RING], 1u);
+      if (ed & 15u) atomicAdd(&counters[pass % COUNTER_RING], 1u);
+      atomicExch(any_change, 1u);
     }
   }
 }
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
                       int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run) {
+                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   k_relax<<<tx * ty, NTHREADS, 0, s>>>(img, img_stride, keys, h, w, tx, ty, max_level, pass, stamps,
-                                       counters, overflow, tiles_run);
+                                       counters, overflow, tiles_run, any_change);
   return hipGetLastError();
 }
 
@@ -277,7 +279,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
 
 __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                       int H, int W, int tilesX, int tilesY, uint32_t pass,
-                                                      uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run) {
+                                                      uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change) {
   __shared__ uint32_t sB[LP][LP];
   __shared__ uint32_t s_edges;
 
@@ -309,7 +311,11 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
 #pragma unroll
   for (int i = 0; i < STRIP; ++i) {
     const uint32_t k = sB[ly0 + i][lx];
-    if (k != 0u && k != KEY_INF) {
+    const int gy = gy0 + i;
+    // flooded pixels are interior pixels (lib.rs:220-222).  On a row block of a larger field the
+    // first/last local rows are halo copies whose down/up neighbour is not here, so their parent
+    // cannot be decided locally: they are left to the owning rank.
+    if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
       const uint32_t d = sB[ly0 + i + 1][lx], r = sB[ly0 + i][lx + 1];
       const uint32_t l = sB[ly0 + i][lx - 1];
       const uint32_t dir = d < k ? 0u : (r < k ? 1u : (l < k ? 2u : 3u));   // at a fixpoint one of the four is < k
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
   if (strip == (NTHREADS / 64) - 1 && (changed_mask >> (STRIP - 1))) e |= 2u;
   if (lane == 0 && changed_mask) e |= 4u;
   if (lane == 63 && changed_mask) e |= 8u;
+  if (changed_mask) e |= 16u;                                             // anything at all
   if (e) atomicOr(&s_edges, e);
   __syncthreads();
   if (tid == 0) {
@@ -388,15 +395,16 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
       if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
       if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
       if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
-      atomicAdd(&counters[pass % COUNTER_RING], 1u);
+      if (ed & 15u) atomicAdd(&counters[pass % COUNTER_RING], 1u);
+      atomicExch(any_change, 1u);
     }
   }
 }
 
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run) {
+                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change) {
   const int tx = tiles_of(w), ty = tiles_of(h);
-  k_resolve<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ty, pass, stamps, counters, tiles_run);
+  k_resolve<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ty, pass, stamps, counters, tiles_run, any_change);
   return hipGetLastError();
 }
 

@@ -1,0 +1,138 @@
+"""World-size-2 (and 3) rehearsal of the multi-GPU drivers on CPU with the gloo backend:
+the tiled single-field path (row blocks + halo exchange + 1-word all-reduce) must be bit-exact
+with the single-domain oracle, and slice sharding must cover a batch exactly once."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__ as ge
+import cases
+import oracle_lib as ol
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tiled_worker(rank, world, port, img, seeds, max_level, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        from numpy_engine import NumpyBlockEngine
+        r0, r1, lo, hi = wd.row_block(img.shape[0], rank, world)
+        loc, col = wd.local_seeds(seeds.astype(np.int64), lo, hi)
+        block = NumpyBlockEngine(img[lo:hi], loc.numpy(), col.numpy(), max_level)
+        owned, rounds = wd.segment_tiled(block, rank, world)
+        assert owned.shape[0] == r1 - r0
+        np.save(os.path.join(outdir, f"part{rank}.npy"), owned.numpy().view(np.uint32))
+        np.save(os.path.join(outdir, f"rounds{rank}.npy"), np.array([rounds]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_tiled(img, seeds, world, max_level=254):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_tiled_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), max_level, d),
+                 nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"part{r}.npy")) for r in range(world)]
+        rounds = [int(np.load(os.path.join(d, f"rounds{r}.npy"))[0]) for r in range(world)]
+    assert len(set(rounds)) == 1                     # every rank takes part in every exchange
+    return np.concatenate(parts, axis=0), rounds[0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiled_field_is_bit_exact_with_single_domain(world):
+    img = cases.field(61, 48, 3)
+    seeds = ol.find_local_minima(img)
+    got, rounds = _run_tiled(img, seeds, world)
+    assert (got == ol.segment(img, seeds)).all()
+    assert rounds >= 4                               # at least one productive + one quiet round per phase
+
+
+def test_tiled_field_long_paths_cross_the_seam_many_times():
+    # a serpentine corridor that crosses the block boundary on every lap: many exchange rounds
+    img = np.full((40, 30), 255, np.uint8)
+    for c in range(1, 29, 2):
+        img[1:39, c] = 4
+        img[38 if (c // 2) % 2 == 0 else 1, c + 1] = 4
+    seeds = [(1, 1)]
+    want = ol.segment(img, seeds)
+    got, rounds = _run_tiled(img, seeds, 2)
+    assert (got == want).all()
+    assert rounds > 10
+
+
+def test_tiled_field_seeds_on_halo_rows_and_low_max_level():
+    img = cases.smooth_field(50, 40, 5)
+    r0, r1, lo, hi = 25, 50, 24, 50                   # world 2: rank 1 owns rows 25.., halo row 24
+    seeds = [(24, 7), (25, 20), (23, 30), (26, 31), (10, 10), (40, 5)]
+    for maxlvl in (60, 254):
+        got, _ = _run_tiled(img, seeds, 2, max_level=maxlvl)
+        assert (got == ol.segment(img, seeds, max_level=maxlvl)).all()
+
+
+def test_row_blocks_and_slice_sharding_partition_exactly():
+    pkg = ge.load_package()
+    import importlib
+    wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+    for h, world in ((61, 2), (64, 8), (7, 3), (32768, 8)):
+        rows = []
+        for r in range(world):
+            r0, r1, lo, hi = wd.row_block(h, r, world)
+            assert lo == (r0 - 1 if r > 0 else r0) and hi == (r1 + 1 if r < world - 1 else r1)
+            rows += list(range(r0, r1))
+        assert rows == list(range(h))
+    for n, world in ((64, 8), (5, 2), (3, 4)):
+        got = sorted(i for r in range(world) for i in wd.shard_slices(n, r, world))
+        assert got == list(range(n))
+    assert pkg is not None
+
+
+def _batch_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        mine = wd.shard_slices(5, rank, world)
+        # independent slices: no collective on the data path; only the timing reduction of bench.py
+        px = 0
+        for i in mine:
+            img = cases.field(24, 24, 100 + i)
+            out = ol.segment(img, ol.find_local_minima(img))
+            np.save(os.path.join(outdir, f"slice{i}.npy"), out)
+            px += img.size
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # bench.py takes the max time over ranks
+        tot = torch.tensor([px], dtype=torch.int64)
+        dist.all_reduce(tot)
+        if rank == 0:
+            np.save(os.path.join(outdir, "summary.npy"), np.array([t.item(), tot.item()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_independent_slices_shard_without_data_collective():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_batch_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        tmax, total = np.load(os.path.join(d, "summary.npy"))
+        assert tmax == 2.0 and total == 5 * 24 * 24
+        for i in range(5):
+            img = cases.field(24, 24, 100 + i)
+            assert (np.load(os.path.join(d, f"slice{i}.npy")) == ol.segment(img, ol.find_local_minima(img))).all()
