@@ -55,6 +55,7 @@ struct ws_ctx {
   std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
+  int relax_ph = 8;                // 0 = first-generation k_relax (64x64 LDS tiles); 8 / 16 = k_relax2 patch height
 };
 
 namespace {
@@ -209,8 +210,11 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   }
   if (n == 0) return WS_OK;
 
-  rc = pass_loop(c, flags, ntiles, &c->stats.relax_passes, [&](uint32_t pass) {
+  rc = pass_loop(c, flags, c->relax_ph ? relax2_tiles(ph, pw, c->relax_ph) : ntiles, &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
+    if (c->relax_ph)
+      return relax2_pass(c->stream, c->relax_ph, d_img, stride, keys, ph, pw, max_level, pass, stamps, flags + FLAG_COUNTERS,
+                         flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps,
                       flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
   });
@@ -223,12 +227,18 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
   if (c->pinned[COUNTER_RING]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
 
-  rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
+  if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
-    return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, flags + FLAG_COUNTERS,
-                        flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
-  });
-  if (rc) return rc;
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw));
+    c->stats.resolve_passes = 2;
+  } else {
+    rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
+      Span sp(c, KC_RESOLVE);
+      return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, flags + FLAG_COUNTERS,
+                          flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
+    });
+    if (rc) return rc;
+  }
   c->stats.launches_resolve = c->stats.resolve_passes;
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TILES_RELAX], flags + FLAG_TILES_RELAX, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
@@ -441,6 +451,10 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   if (ok && own) ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   if (ok && !own) c->stream = (hipStream_t)stream;
   c->own_stream = own;
+  if (const char *e = std::getenv("WS_RELAX_PH")) {      // A/B switch for measurements: 0, 8 or 16
+    const int v = std::atoi(e);
+    if (v == 0 || v == 8 || v == 16) c->relax_ph = v;
+  }
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -654,7 +668,10 @@ int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY_CHANGE, 0, sizeof(uint32_t), c->stream));
   uint32_t passes = 0;
-  rc = pass_loop(c, flags, ntiles, &passes, [&](uint32_t pass) {
+  rc = pass_loop(c, flags, c->relax_ph ? relax2_tiles((int)h, (int)w, c->relax_ph) : ntiles, &passes, [&](uint32_t pass) {
+    if (c->relax_ph)
+      return relax2_pass(c->stream, c->relax_ph, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps,
+                         flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
     return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, flags + FLAG_COUNTERS,
                       flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
   });

@@ -46,6 +46,15 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
                         uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change);
 
+// second-generation relaxation (ws_relax2.hip): register patches of 4 x ph pixels, tiles of 256 x 4*ph
+size_t relax2_tiles(int h, int w, int ph);
+hipError_t relax2_pass(hipStream_t s, int ph, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
+                       uint32_t max_level, uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *overflow,
+                       uint32_t *tiles_run, uint32_t *any_change);
+
+// label resolve without a launch loop (pointer jumping in LDS + reference chase); needs h*w < 2^31
+hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w);
+
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);
 

@@ -408,6 +408,114 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
   return hipGetLastError();
 }
 
+// ------------------------------------ fused engine: label resolve, two-launch form ----
+//
+// Same forest as k_resolve, but resolved without iterating over launches:
+//   k_resolve_local  every tile builds the parent pointers of its pixels in LDS and collapses the
+//                    in-tile part of the forest by pointer jumping (log2(depth) rounds).  A pixel
+//                    whose root is a seed of the tile gets that seed's colour; a pixel whose chain
+//                    leaves the tile gets a REFERENCE to the halo pixel where it leaves
+//                    (REF_BIT | global pixel index) instead of a colour.
+//   k_resolve_chase  follows references until a colour is found.  A reference always points to a
+//                    pixel with a strictly smaller stamp, so chains end at a seed; concurrent
+//                    updates only ever replace a reference by what it resolves to.
+// Needs pixel indices < 2^31 (planes up to 46340^2); larger planes use the k_resolve loop.
+
+constexpr uint32_t REF_BIT = 0x80000000u;
+
+__global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
+                                                            int H, int W, int tilesX) {
+  __shared__ uint32_t sB[LP * LP];
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, strip = tid >> 6;
+  const int x0 = tile_x * TS, y0 = tile_y * TS;
+  const int lx = lane + 1, ly0 = strip * STRIP + 1;
+  const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
+
+  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
+    const int ly = idx / LP, lxx = idx - ly * LP;
+    const int gy = y0 - 1 + ly, gxx = x0 - 1 + lxx;
+    uint32_t v = KEY_INF;
+    if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) v = keys[(size_t)gy * W + gxx];
+    sB[idx] = v;
+  }
+  __syncthreads();
+
+  uint32_t P[STRIP];
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) {
+    const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
+    const uint32_t k = sB[cell];
+    const int gy = gy0 + i;
+    uint32_t p = cell;
+    // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U (lib.rs:190, 245)
+    if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
+      const uint32_t d = sB[cell + LP], r = sB[cell + 1], l = sB[cell - 1];
+      p = d < k ? cell + LP : (r < k ? cell + 1 : (l < k ? cell - 1 : cell - LP));
+    }
+    P[i] = p;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < LP * LP; idx += NTHREADS) sB[idx] = (uint32_t)idx;     // halo cells are roots
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = P[i];
+  __syncthreads();
+
+  for (;;) {                                   // pointer jumping: P <- P(P)
+    int changed = 0;
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const uint32_t q = P[i];
+      const uint32_t g = sB[q];
+      if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+
+  if (gx < W) {
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const int gy = gy0 + i;
+      const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
+      const uint32_t r = P[i];
+      if (r != cell && gy < H) {
+        const int rly = (int)(r / LP), rlx = (int)(r - (uint32_t)rly * LP);
+        const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - 1 + rlx);
+        const bool inside = rly >= 1 && rly <= TS && rlx >= 1 && rlx <= TS;
+        labels[(size_t)gy * W + gx] = inside ? labels[rg] : (REF_BIT | (uint32_t)rg);
+      }
+    }
+  }
+}
+
+__global__ void k_resolve_chase(uint32_t *labels, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    uint32_t v = labels[i];
+    if (v & REF_BIT) {
+      // bounded: a chain visits strictly decreasing stamps, so it is shorter than the pixel count
+      for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
+        v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      labels[i] = v;
+    }
+  }
+}
+
+hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w) {
+  const int tx = tiles_of(w), ty = tiles_of(h);
+  const size_t n = (size_t)h * w;
+  if (n == 0) return hipSuccess;
+  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int blocks = (int)((n + 1023) / 1024 < 16384 ? (n + 1023) / 1024 : 16384);
+  k_resolve_chase<<<blocks, 256, 0, s>>>(labels, n);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------ sweep engine: one flood step -------
 //
 // lib.rs:196-257 one-to-one: every interior pixel that is flooded (img <= level),
