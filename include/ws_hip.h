@@ -110,7 +110,7 @@ typedef struct ws_stats {
   uint32_t launches_relax;
   uint32_t launches_resolve;
   uint32_t launches_sweep;
-  uint32_t reserved;
+  uint32_t relax_tile_iterations; /* k_relax2: in-tile sweeps summed over tiles and passes */
 } ws_stats;
 
 /* HookCtx (lib.rs:844-862) as a C callback, invoked once per water level, in order.

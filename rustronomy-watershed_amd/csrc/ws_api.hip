@@ -55,20 +55,32 @@ struct ws_ctx {
   std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
-  int relax_ph = 8;                // 0 = first-generation k_relax (64x64 LDS tiles); 8 / 16 = k_relax2 patch height
+  uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
 };
 
 namespace {
 
-// flags buffer layout (u32 words)
-constexpr int FLAG_COUNTERS = 0;                 // COUNTER_RING words
-constexpr int FLAG_OVERFLOW = COUNTER_RING;      // 1
-constexpr int FLAG_SEED_ERR = COUNTER_RING + 1;  // 1
-constexpr int FLAG_TILES_RELAX = COUNTER_RING + 2;
-constexpr int FLAG_TILES_RESOLVE = COUNTER_RING + 3;
-constexpr int FLAG_TOTAL = COUNTER_RING + 4;     // minima total
-constexpr int FLAG_ANY_CHANGE = COUNTER_RING + 5;
-constexpr int FLAG_WORDS = COUNTER_RING + 8;
+// flags buffer layout (u32 words); the pinned host mirror uses the same offsets
+constexpr int FLAG_EDGE = 0;                                 // [COUNTER_RING][FLAG_SLOT] striped "a tile edge changed"
+constexpr int FLAG_ANY = COUNTER_RING * FLAG_SLOT;           // [FLAG_SLOT] striped "any pixel changed"
+constexpr int FLAG_STATS = FLAG_ANY + FLAG_SLOT;             // [2][FLAG_SLOT] striped tile / sweep counters (profiling)
+constexpr int FLAG_MISC = FLAG_STATS + 2 * FLAG_SLOT;
+constexpr int FLAG_OVERFLOW = FLAG_MISC + 0;
+constexpr int FLAG_SEED_ERR = FLAG_MISC + 1;
+constexpr int FLAG_TOTAL = FLAG_MISC + 2;                    // minima total
+constexpr int FLAG_SWEEP = FLAG_MISC + 3;                    // sweep engine: tiles coloured in the last step
+constexpr int FLAG_WORDS = FLAG_MISC + 16;
+
+PassFlags make_pf(ws_ctx *c) {
+  uint32_t *f = (uint32_t *)c->flags.p;
+  return PassFlags{f + FLAG_EDGE, f + FLAG_ANY, f + FLAG_OVERFLOW, c->profiling ? f + FLAG_STATS : nullptr};
+}
+
+bool slot_nonzero(const uint32_t *slot) {
+  uint32_t any = 0;
+  for (int i = 0; i < NSTRIPE; ++i) any |= slot[i * STRIPE_STRIDE];
+  return any != 0;
+}
 
 int fail(ws_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
   if (c) {
@@ -165,24 +177,25 @@ int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *
 
 // ---- fused engine ------------------------------------------------------------------------
 
-// Runs `launch(pass)` until a pass reports zero changed tile edges.  The next pass is
-// launched before the previous counter is read (one speculative pass, a no-op when the
-// previous one converged), so the host never stalls the stream between passes.
+// Runs `launch(pass)` until a pass reports zero changed tile edges.  The host stays
+// PASS_LOOKAHEAD passes ahead of the flag it reads (a pass launched after convergence exits in
+// every tile at once, ~5 us), so the stream never waits for a host round trip between passes.
+constexpr uint32_t PASS_LOOKAHEAD = 3;
 template <class F>
 int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch) {
   HIP_TRY(c, hipMemsetAsync(c->stamps.p, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_COUNTERS, 0, COUNTER_RING * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_EDGE, 0, COUNTER_RING * FLAG_SLOT * sizeof(uint32_t), c->stream));
   uint32_t pass = 0;
   for (;; ++pass) {
     HIP_TRY(c, launch(pass));
     const int slot = pass % COUNTER_RING;
-    HIP_TRY(c, hipMemcpyAsync(&c->pinned[slot], d_flags + FLAG_COUNTERS + slot, sizeof(uint32_t),
-                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_EDGE + slot * FLAG_SLOT], d_flags + FLAG_EDGE + slot * FLAG_SLOT,
+                              FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
-    if (pass >= 1) {
-      const int prev = (pass - 1) % COUNTER_RING;
+    if (pass >= PASS_LOOKAHEAD) {
+      const int prev = (pass - PASS_LOOKAHEAD) % COUNTER_RING;
       HIP_TRY(c, hipEventSynchronize(c->ring_ev[prev]));
-      if (c->pinned[prev] == 0) break;
+      if (!slot_nonzero(&c->pinned[FLAG_EDGE + prev * FLAG_SLOT])) break;
     }
   }
   *passes_out = pass + 1;
@@ -203,29 +216,27 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
 
   {
     Span sp(c, KC_OTHER);
-    HIP_TRY(c, fill_u32(c->stream, keys, n, KEY_INF));
     HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 4 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, keys, flags + FLAG_SEED_ERR));
+    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
+    if (c->profiling) HIP_TRY(c, hipMemsetAsync(flags + FLAG_STATS, 0, 2 * FLAG_SLOT * sizeof(uint32_t), c->stream));
+    // stamps are not touched here: relaxation pass 0 derives them from the painted label plane
+    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, nullptr, flags + FLAG_SEED_ERR));
   }
   if (n == 0) return WS_OK;
 
-  rc = pass_loop(c, flags, c->relax_ph ? relax2_tiles(ph, pw, c->relax_ph) : ntiles, &c->stats.relax_passes, [&](uint32_t pass) {
+  const PassFlags pf = make_pf(c);
+  rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
-    if (c->relax_ph)
-      return relax2_pass(c->stream, c->relax_ph, d_img, stride, keys, ph, pw, max_level, pass, stamps, flags + FLAG_COUNTERS,
-                         flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
-    return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps,
-                      flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
+    return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters, d_labels);
   });
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
 
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
-  if (c->pinned[COUNTER_RING]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+  if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
 
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
@@ -234,17 +245,19 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
       Span sp(c, KC_RESOLVE);
-      return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, flags + FLAG_COUNTERS,
-                          flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
+      return resolve_pass(c->stream, keys, d_labels, ph, pw, pass, stamps, pf);
     });
     if (rc) return rc;
   }
   c->stats.launches_resolve = c->stats.resolve_passes;
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TILES_RELAX], flags + FLAG_TILES_RELAX, 2 * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->stats.tiles_run_relax = c->pinned[FLAG_TILES_RELAX];
-  c->stats.tiles_run_resolve = c->pinned[FLAG_TILES_RESOLVE];
+  if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
+    HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_STATS], flags + FLAG_STATS, 2 * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < NSTRIPE; ++i) {
+      c->stats.tiles_run_relax += c->pinned[FLAG_STATS + i * STRIPE_STRIDE];
+      c->stats.relax_tile_iterations += c->pinned[FLAG_STATS + FLAG_SLOT + i * STRIPE_STRIDE];
+    }
+  }
   c->have_keys = true;
   c->last_h = ph;
   c->last_w = pw;
@@ -267,24 +280,24 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   HIP_TRY(c, hipMemsetAsync(cur, 0, n * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
 
   for (uint32_t lvl = 0; lvl <= max_level; ++lvl) {
     for (;;) {
       if (n == 0) break;
       {
         Span sp(c, KC_SWEEP);
-        HIP_TRY(c, hipMemsetAsync(flags + FLAG_COUNTERS, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(c, flood_step(c->stream, d_img, stride, cur, nxt, ph, pw, lvl, flags + FLAG_COUNTERS));
+        HIP_TRY(c, hipMemsetAsync(flags + FLAG_SWEEP, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, flood_step(c->stream, d_img, stride, cur, nxt, ph, pw, lvl, flags + FLAG_SWEEP));
         c->stats.sweep_steps++;
       }
-      HIP_TRY(c, hipMemcpyAsync(&c->pinned[0], flags + FLAG_COUNTERS, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_SWEEP], flags + FLAG_SWEEP, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       std::swap(cur, nxt);                 // an empty step copies the plane, so either buffer is current
-      if (c->pinned[0] == 0) break;        // lib.rs:1733-1735
+      if (c->pinned[FLAG_SWEEP] == 0) break;   // lib.rs:1733-1735
     }
     rc = after_level(lvl, cur);
     if (rc) return rc;
@@ -451,10 +464,7 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   if (ok && own) ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   if (ok && !own) c->stream = (hipStream_t)stream;
   c->own_stream = own;
-  if (const char *e = std::getenv("WS_RELAX_PH")) {      // A/B switch for measurements: 0, 8 or 16
-    const int v = std::atoi(e);
-    if (v == 0 || v == 8 || v == 16) c->relax_ph = v;
-  }
+  if (const char *e = std::getenv("WS_DEBUG_MAXIT")) c->debug_max_iters = (uint32_t)std::atoi(e);
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -646,11 +656,11 @@ int ws_block_init(ws_ctx *c, size_t h, size_t w, const uint32_t *d_seeds_rc, con
   const size_t n = h * w;
   HIP_TRY(c, fill_u32(c->stream, d_keys, n, KEY_INF));
   if (n) HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 4 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds_rc, d_colours, n_seeds, (int)h, (int)w, d_labels, d_keys, flags + FLAG_SEED_ERR));
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pinned[COUNTER_RING + 1]) return fail(c, WS_ERR_SEED_OOB, "seed outside the local plane");
+  if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the local plane");
   return WS_OK;
 }
 
@@ -666,22 +676,20 @@ int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   if ((rc = ensure(c, c->stamps, ntiles * 4 * 2 * sizeof(uint32_t)))) return rc;
   uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY_CHANGE, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY, 0, FLAG_SLOT * sizeof(uint32_t), c->stream));
+  PassFlags pf = make_pf(c);
+  pf.stats = nullptr;
   uint32_t passes = 0;
-  rc = pass_loop(c, flags, c->relax_ph ? relax2_tiles((int)h, (int)w, c->relax_ph) : ntiles, &passes, [&](uint32_t pass) {
-    if (c->relax_ph)
-      return relax2_pass(c->stream, c->relax_ph, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps,
-                         flags + FLAG_COUNTERS, flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
-    return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, flags + FLAG_COUNTERS,
-                      flags + FLAG_OVERFLOW, flags + FLAG_TILES_RELAX, flags + FLAG_ANY_CHANGE);
+  rc = pass_loop(c, flags, relax_tiles((int)h, (int)w), &passes, [&](uint32_t pass) {
+    return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, pf, c->debug_max_iters);
   });
   if (rc) return rc;
   c->stats.relax_passes += passes;
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[COUNTER_RING], flags + FLAG_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY_CHANGE], flags + FLAG_ANY_CHANGE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY], flags + FLAG_ANY, FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pinned[COUNTER_RING]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
-  *changed = c->pinned[FLAG_ANY_CHANGE] != 0;
+  if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+  *changed = slot_nonzero(&c->pinned[FLAG_ANY]);
   return WS_OK;
 }
 
@@ -695,17 +703,18 @@ int ws_block_resolve(ws_ctx *c, const uint32_t *d_keys, uint32_t *d_labels, size
   int rc;
   if ((rc = ensure(c, c->stamps, ntiles * 4 * 2 * sizeof(uint32_t)))) return rc;
   uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
-  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY_CHANGE, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY, 0, FLAG_SLOT * sizeof(uint32_t), c->stream));
+  PassFlags pf = make_pf(c);
+  pf.stats = nullptr;
   uint32_t passes = 0;
   rc = pass_loop(c, flags, ntiles, &passes, [&](uint32_t pass) {
-    return resolve_pass(c->stream, d_keys, d_labels, (int)h, (int)w, pass, stamps, flags + FLAG_COUNTERS,
-                        flags + FLAG_TILES_RESOLVE, flags + FLAG_ANY_CHANGE);
+    return resolve_pass(c->stream, d_keys, d_labels, (int)h, (int)w, pass, stamps, pf);
   });
   if (rc) return rc;
   c->stats.resolve_passes += passes;
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY_CHANGE], flags + FLAG_ANY_CHANGE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_ANY], flags + FLAG_ANY, FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  *changed = c->pinned[FLAG_ANY_CHANGE] != 0;
+  *changed = slot_nonzero(&c->pinned[FLAG_ANY]);
   return WS_OK;
 }
 

@@ -20,14 +20,24 @@ namespace wsk {
 constexpr uint32_t KEY_INF = 0xFF000000u;   // level 255 can never open (NEVER_FILL, lib.rs:141)
 constexpr uint32_t RING_MASK = 0x00FFFFFFu;
 
-constexpr int TS = 64;        // tile side in pixels
+constexpr int TS = 64;        // tile side of the label-resolve kernels
 constexpr int LP = TS + 2;    // LDS tile side including the 1-px halo
-constexpr int STRIP = 16;     // rows per thread: 256 threads = 64 columns x 4 strips
+constexpr int STRIP = 16;     // rows per thread there: 256 threads = 64 columns x 4 strips
 constexpr int NTHREADS = 256;
-constexpr int COUNTER_RING = 8;   // per-pass "edges changed" counters, reused cyclically
 
-struct Launch {
-  hipStream_t stream;
+// Per-pass convergence words.  Workgroups never share an atomic: a tile that changed stores 1
+// (plain, idempotent) into the stripe blockIdx % NSTRIPE of the pass's slot; stripes sit on their
+// own 64-byte lines.  The host reads one slot (NSTRIPE lines) per pass.
+constexpr int COUNTER_RING = 8;                   // slots reused cyclically, one per pass
+constexpr int NSTRIPE = 64;
+constexpr int STRIPE_STRIDE = 16;                 // words between stripes (64 bytes)
+constexpr int FLAG_SLOT = NSTRIPE * STRIPE_STRIDE;   // words per slot
+
+struct PassFlags {
+  uint32_t *edge_changed;   // [COUNTER_RING][FLAG_SLOT]: a tile edge changed in pass (p % COUNTER_RING)
+  uint32_t *any_change;     // [FLAG_SLOT]: any pixel changed (row-block API)
+  uint32_t *overflow;       // 1 word: ring field carried into the level field
+  uint32_t *stats;          // nullptr unless profiling: [2][FLAG_SLOT] striped tile / sweep counters
 };
 
 // --- launch wrappers (ws_kernels.hip) ---------------------------------------------------
@@ -40,18 +50,16 @@ hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);
 
-hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
-                      int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change);
+// relaxation (ws_relax.hip): 4x4 register patches, 256 x 32 tiles, row/column sweeps
+size_t relax_tiles(int h, int w);
+hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
+                      uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
+                      const uint32_t *seed_labels = nullptr);   // non-null: pass 0 derives the stamps from this label plane
+
+// label resolve, iterative form (row blocks of a tiled field, planes >= 2^31 pixels): 64x64 tiles
+size_t resolve_tiles(int h, int w);
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change);
-
-// second-generation relaxation (ws_relax2.hip): register patches of 4 x ph pixels, tiles of 256 x 4*ph
-size_t relax2_tiles(int h, int w, int ph);
-hipError_t relax2_pass(hipStream_t s, int ph, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
-                       uint32_t max_level, uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *overflow,
-                       uint32_t *tiles_run, uint32_t *any_change);
-
+                        uint32_t pass, uint32_t *stamps, PassFlags pf);
 // label resolve without a launch loop (pointer jumping in LDS + reference chase); needs h*w < 2^31
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w);
 

@@ -65,26 +65,45 @@ hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w
   return hipGetLastError();
 }
 
-// lib.rs:1670-1677: colour i+1 at seed i; a later duplicate overwrites an earlier one
-// (atomicMax keeps the largest index = the last writer of the sequential loop).
-__global__ void k_scatter_seeds(const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw, uint32_t *labels,
-                                uint32_t *keys, uint32_t *err_flag) {
+// lib.rs:1670-1677: colour i+1 at seed i; a later duplicate overwrites an earlier one, i.e. the
+// LARGEST colour painted on a pixel wins.  One atomicMax per seed costs ~35 ns of memory-side atomic
+// each (7.3 M seeds: 250 us), so the painting is split: plain stores first (duplicates race, any of
+// them lands), then a fix-up pass in which a seed whose colour is larger than what it finds there
+// raises the pixel with atomicMax -- only duplicate seeds ever issue an atomic.
+__global__ void k_scatter_seeds(const uint32_t *__restrict__ seeds_rc, const uint32_t *__restrict__ colours, size_t n, int ph,
+                                int pw, uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
-    const uint32_t r = seeds_rc[2 * i], c = seeds_rc[2 * i + 1];
-    if (r >= (uint32_t)ph || c >= (uint32_t)pw) { atomicExch(err_flag, 1u); continue; }
-    const size_t p = (size_t)r * pw + c;
-    atomicMax(&labels[p], colours ? colours[i] : (uint32_t)(i + 1));
+    const uint2 rc = reinterpret_cast<const uint2 *>(seeds_rc)[i];
+    if (rc.x >= (uint32_t)ph || rc.y >= (uint32_t)pw) { atomicExch(err_flag, 1u); continue; }
+    const size_t p = (size_t)rc.x * pw + rc.y;
+    labels[p] = colours ? colours[i] : (uint32_t)(i + 1);
     if (keys) keys[p] = 0u;
+  }
+}
+
+__global__ void k_scatter_fixup(const uint32_t *__restrict__ seeds_rc, const uint32_t *__restrict__ colours, size_t n, int ph,
+                                int pw, uint32_t *labels) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint2 rc = reinterpret_cast<const uint2 *>(seeds_rc)[i];
+    if (rc.x >= (uint32_t)ph || rc.y >= (uint32_t)pw) continue;
+    const size_t p = (size_t)rc.x * pw + rc.y;
+    const uint32_t mine = colours ? colours[i] : (uint32_t)(i + 1);
+    if (labels[p] < mine) atomicMax(&labels[p], mine);
   }
 }
 
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
   if (n == 0) return hipSuccess;
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
   k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, keys, err_flag);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  k_scatter_fixup<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels);
   return hipGetLastError();
 }
 
@@ -125,16 +144,11 @@ hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *l
   return hipGetLastError();
 }
 
-// ------------------------------------------------------- fused engine: relaxation ----
+// ------------------------------------------------------- tile scheduling helper ----
 //
-// One workgroup = one 64x64 tile held in LDS with its 1-px halo.  256 threads: lane = x
-// (so every LDS row access is 64 consecutive dwords: conflict free), wave = 16-row strip.
-// Each thread keeps its 16 stamps and 16 bases in registers and sweeps its strip down
-// then up (Gauss-Seidel inside the strip), reading left/right/strip-end neighbours from
-// LDS.  The recurrence is monotone, so any update order reaches the same fixpoint; the
-// tile iterates until a full sweep changes nothing (workgroup OR-reduction), then writes
-// the changed stamps back.  Tiles whose halo did not change since their last run exit at
-// once (edge stamps); the host stops when a pass changes no tile edge.
+// A tile re-runs in pass p only if a neighbour changed the edge it shares with it in pass p-1
+// (edge stamps, double buffered by pass parity; layout per tile: 0 top, 1 bottom, 2 left, 3 right;
+// value = pass + 1 of the writer).
 
 __device__ __forceinline__ bool tile_must_run(const uint32_t *stamps_prev, int tx, int ty, int tilesX,
                                               int tilesY, uint32_t pass) {
@@ -149,125 +163,7 @@ __device__ __forceinline__ bool tile_must_run(const uint32_t *stamps_prev, int t
   return run;
 }
 
-__global__ __launch_bounds__(NTHREADS) void k_relax(const uint8_t *__restrict__ img, size_t img_stride,
-                                                    uint32_t *keys, int H, int W, int tilesX, int tilesY,
-                                                    uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                                                    uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change) {
-  __shared__ uint32_t sT[LP][LP];
-  __shared__ uint32_t s_edges;
-
-  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
-  const size_t ntiles = (size_t)tilesX * tilesY;
-  const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
-  uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(pass + 1) % COUNTER_RING] = 0;
-  if (!tile_must_run(stamps_prev, tile_x, tile_y, tilesX, tilesY, pass)) return;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, strip = tid >> 6;
-  const int x0 = tile_x * TS, y0 = tile_y * TS;
-  if (tid == 0) { s_edges = 0; atomicAdd(tiles_run, 1u); }
-
-  // tile + halo -> LDS (out-of-image = never coloured)
-  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
-    const int ly = idx / LP, lx = idx - ly * LP;
-    const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-    uint32_t v = KEY_INF;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = keys[(size_t)gy * W + gx];
-    sT[ly][lx] = v;
-  }
-
-  // this thread's column strip: bases in registers
-  const int gx = x0 + lane;
-  const int gy0 = y0 + strip * STRIP;
-  uint32_t base[STRIP], own[STRIP];
-#pragma unroll
-  for (int i = 0; i < STRIP; ++i) {
-    const int gy = gy0 + i;
-    uint32_t b = KEY_INF;
-    // only interior pixels are ever flooded (3x3 windows: lib.rs:220-222)
-    if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
-      const uint32_t v = img[(size_t)gy * img_stride + gx];
-      if (v <= max_level) b = (v << 24) | 1u;               // lib.rs:224: img <= level
-    }
-    base[i] = b;
-  }
-  __syncthreads();
-  const int lx = lane + 1, ly0 = strip * STRIP + 1;
-#pragma unroll
-  for (int i = 0; i < STRIP; ++i) own[i] = sT[ly0 + i][lx];
-
-  uint32_t changed_mask = 0;
-  for (;;) {
-    int changed = 0;
-    // downward sweep
-#pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      const uint32_t l = sT[ly0 + i][lx - 1], r = sT[ly0 + i][lx + 1];
-      const uint32_t u = (i == 0) ? sT[ly0 - 1][lx] : own[i - 1];
-      const uint32_t d = (i == STRIP - 1) ? sT[ly0 + STRIP][lx] : own[i + 1];
-      const uint32_t m = min(min(l, r), min(u, d));
-      const uint32_t n = min(own[i], max(base[i], m + 1u));
-      if (n != own[i]) { own[i] = n; sT[ly0 + i][lx] = n; changed = 1; changed_mask |= 1u << i; }
-    }
-    // upward sweep
-#pragma unroll
-    for (int i = STRIP - 1; i >= 0; --i) {
-      const uint32_t l = sT[ly0 + i][lx - 1], r = sT[ly0 + i][lx + 1];
-      const uint32_t u = (i == 0) ? sT[ly0 - 1][lx] : own[i - 1];
-      const uint32_t d = (i == STRIP - 1) ? sT[ly0 + STRIP][lx] : own[i + 1];
-      const uint32_t m = min(min(l, r), min(u, d));
-      const uint32_t n = min(own[i], max(base[i], m + 1u));
-      if (n != own[i]) { own[i] = n; sT[ly0 + i][lx] = n; changed = 1; changed_mask |= 1u << i; }
-    }
-    if (!__syncthreads_or(changed)) break;
-  }
-
-  // write back what changed; coalesced rows of 64 dwords per wave
-  uint32_t ovf = 0;
-  if (gx < W) {
-#pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      const int gy = gy0 + i;
-      if ((changed_mask >> i) & 1u) {
-        if (gy < H) keys[(size_t)gy * W + gx] = own[i];
-        // a finite non-seed stamp with ring 0 can only come from a ring-field carry
-        ovf |= (own[i] != 0u && own[i] < KEY_INF && (own[i] & RING_MASK) == 0u);
-      }
-    }
-  }
-  if (ovf) atomicExch(overflow, 1u);
-
-  uint32_t e = 0;
-  if (strip == 0 && (changed_mask & 1u)) e |= 1u;                         // top row
-  if (strip == (NTHREADS / 64) - 1 && (changed_mask >> (STRIP - 1))) e |= 2u;  // bottom row
-  if (lane == 0 && changed_mask) e |= 4u;                                 // left column
-  if (lane == 63 && changed_mask) e |= 8u;                                // right column
-  if (changed_mask) e |= 16u;                                             // anything at all
-  if (e) atomicOr(&s_edges, e);
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t ed = s_edges;
-    if (ed) {
-      const size_t t = (size_t)tile_y * tilesX + tile_x;
-      if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
-      if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
-      if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
-      if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
-      if (ed & 15u) atomicAdd(&counters[pass % COUNTER_RING], 1u);
-      atomicExch(any_change, 1u);
-    }
-  }
-}
-
-hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h,
-                      int w, uint32_t max_level, uint32_t pass, uint32_t *stamps,
-                      uint32_t *counters, uint32_t *overflow, uint32_t *tiles_run, uint32_t *any_change) {
-  const int tx = tiles_of(w), ty = tiles_of(h);
-  k_relax<<<tx * ty, NTHREADS, 0, s>>>(img, img_stride, keys, h, w, tx, ty, max_level, pass, stamps,
-                                       counters, overflow, tiles_run, any_change);
-  return hipGetLastError();
-}
+size_t resolve_tiles(int h, int w) { return (size_t)tiles_of(w) * tiles_of(h); }
 
 // ---------------------------------------------------- fused engine: label resolve ----
 //
@@ -279,7 +175,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
 
 __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                       int H, int W, int tilesX, int tilesY, uint32_t pass,
-                                                      uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change) {
+                                                      uint32_t *stamps, PassFlags pf) {
   __shared__ uint32_t sB[LP][LP];
   __shared__ uint32_t s_edges;
 
@@ -287,7 +183,8 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
   const size_t ntiles = (size_t)tilesX * tilesY;
   const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
   uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[(pass + 1) % COUNTER_RING] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
+    pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
   if (!tile_must_run(stamps_prev, tile_x, tile_y, tilesX, tilesY, pass)) return;
 
   const int tid = threadIdx.x;
@@ -295,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
   const int x0 = tile_x * TS, y0 = tile_y * TS;
   const int lx = lane + 1, ly0 = strip * STRIP + 1;
   const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
-  if (tid == 0) { s_edges = 0; atomicAdd(tiles_run, 1u); }
+  if (tid == 0) s_edges = 0;
 
   // phase 1: stamps -> LDS, parent directions -> registers
   for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
@@ -395,16 +292,18 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve(const uint32_t *__restrict
       if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
       if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
       if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
-      if (ed & 15u) atomicAdd(&counters[pass % COUNTER_RING], 1u);
-      atomicExch(any_change, 1u);
+      // plain, idempotent stores into striped words (no same-address atomics on the tile path)
+      const uint32_t stripe = (blockIdx.x % NSTRIPE) * STRIPE_STRIDE;
+      if (ed & 15u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
+      pf.any_change[stripe] = 1u;
     }
   }
 }
 
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                        uint32_t pass, uint32_t *stamps, uint32_t *counters, uint32_t *tiles_run, uint32_t *any_change) {
+                        uint32_t pass, uint32_t *stamps, PassFlags pf) {
   const int tx = tiles_of(w), ty = tiles_of(h);
-  k_resolve<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ty, pass, stamps, counters, tiles_run, any_change);
+  k_resolve<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ty, pass, stamps, pf);
   return hipGetLastError();
 }
 
@@ -423,23 +322,66 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 
 constexpr uint32_t REF_BIT = 0x80000000u;
 
+typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX) {
-  __shared__ uint32_t sB[LP * LP];
+  // stamps of the tile and its 1-px halo ring, later overwritten by the parent pointers
+  __shared__ __attribute__((aligned(16))) uint32_t sB[LP * LP];
+  // colours of the tile's own pixels as painted (seeds), so a root's colour is an LDS read
+  __shared__ __attribute__((aligned(16))) uint32_t sL[TS * TS];
+  __shared__ uint32_t s_flag[3];
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, strip = tid >> 6;
   const int x0 = tile_x * TS, y0 = tile_y * TS;
   const int lx = lane + 1, ly0 = strip * STRIP + 1;
   const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
+  if (tid < 3) s_flag[tid] = 0;
 
-  for (int idx = tid; idx < LP * LP; idx += NTHREADS) {
-    const int ly = idx / LP, lxx = idx - ly * LP;
-    const int gy = y0 - 1 + ly, gxx = x0 - 1 + lxx;
-    uint32_t v = KEY_INF;
-    if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) v = keys[(size_t)gy * W + gxx];
-    sB[idx] = v;
+  // ---- loads: unconditional on clamped addresses (see ws_relax.hip), 16 B per lane where the
+  // tile lies inside the image in x and rows are 16-byte aligned
+  const bool fast = (x0 + TS <= W) && (W & 3) == 0;
+  if (fast) {
+    u32x4_r kv[4], lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // 1024 chunks of 4 px: row = id / 16, chunk = id % 16
+      const int id = tid + k * NTHREADS, r = id >> 4, cx = (id & 15) * 4;
+      const size_t g = (size_t)min(y0 + r, H - 1) * W + x0 + cx;
+      kv[k] = *reinterpret_cast<const u32x4_r *>(keys + g);
+      lv[k] = *reinterpret_cast<const u32x4_r *>(labels + g);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int id = tid + k * NTHREADS, r = id >> 4, cx = (id & 15) * 4;
+      const bool ok = y0 + r < H;
+      uint32_t *d = &sB[(r + 1) * LP + cx + 1];
+      d[0] = ok ? kv[k].x : KEY_INF; d[1] = ok ? kv[k].y : KEY_INF; d[2] = ok ? kv[k].z : KEY_INF; d[3] = ok ? kv[k].w : KEY_INF;
+      *reinterpret_cast<u32x4_r *>(&sL[r * TS + cx]) = lv[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {                   // 4096 pixels, 16 per thread, row contiguous across lanes
+      const int id = tid + k * NTHREADS, r = id >> 6, cxx = id & 63;
+      const int gyy = y0 + r, gxx = x0 + cxx;
+      const size_t g = (size_t)min(gyy, H - 1) * W + min(gxx, W - 1);
+      const uint32_t kvv = keys[g], lvv = labels[g];
+      const bool ok = gyy < H && gxx < W;
+      sB[(r + 1) * LP + cxx + 1] = ok ? kvv : KEY_INF;
+      sL[r * TS + cxx] = ok ? lvv : 0u;
+    }
   }
+  {
+    // halo ring: thread t < 64 loads (top, bottom, left, right)[t]
+    const int side = tid >> 6, t = tid & 63;            // 4 sides x 64 positions = 256 threads
+    const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
+    const int hx = side == 2 ? x0 - 1 : (side == 3 ? x0 + TS : x0 + t);
+    const uint32_t v = keys[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
+    const bool ok = hy >= 0 && hy < H && hx >= 0 && hx < W;
+    const int ly = hy - (y0 - 1), lxx = hx - (x0 - 1);
+    sB[ly * LP + lxx] = ok ? v : KEY_INF;
+  }
+  if (tid < 4) sB[(tid & 1 ? LP - 1 : 0) * LP + (tid & 2 ? LP - 1 : 0)] = KEY_INF;   // corners: never a parent
   __syncthreads();
 
   uint32_t P[STRIP];
@@ -463,15 +405,21 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
   for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = P[i];
   __syncthreads();
 
-  for (;;) {                                   // pointer jumping: P <- P(P)
-    int changed = 0;
+  for (uint32_t it = 0;; ++it) {               // pointer jumping: P <- P(P)
+    bool changed = false;
 #pragma unroll
     for (int i = 0; i < STRIP; ++i) {
       const uint32_t q = P[i];
       const uint32_t g = sB[q];
-      if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = 1; }
+      if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = true; }
     }
-    if (!__syncthreads_or(changed)) break;
+    // one barrier per round: flag slot it % 3 (see k_relax)
+    const uint32_t slot = it % 3;
+    if (__builtin_amdgcn_ballot_w64(changed) != 0 && lane == 0) s_flag[slot] = 1;
+    __syncthreads();
+    const bool again = s_flag[slot] != 0;
+    if (tid == 0) s_flag[(slot + 2) % 3] = 0;
+    if (!again) break;
   }
 
   if (gx < W) {
@@ -482,9 +430,9 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
       const uint32_t r = P[i];
       if (r != cell && gy < H) {
         const int rly = (int)(r / LP), rlx = (int)(r - (uint32_t)rly * LP);
-        const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - 1 + rlx);
         const bool inside = rly >= 1 && rly <= TS && rlx >= 1 && rlx <= TS;
-        labels[(size_t)gy * W + gx] = inside ? labels[rg] : (REF_BIT | (uint32_t)rg);
+        const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - 1 + rlx);
+        labels[(size_t)gy * W + gx] = inside ? sL[(rly - 1) * TS + (rlx - 1)] : (REF_BIT | (uint32_t)rg);
       }
     }
   }

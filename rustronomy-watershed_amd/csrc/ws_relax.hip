@@ -1,0 +1,354 @@
+// ws_relax.hip -- relaxation kernel of the fused engine (gfx950, wave64).
+//
+// Fixpoint: key(p) = max(base(p), 1 + min over the 4 neighbours of key(q))   (ws_common.hpp).
+//
+// Layout
+//   * a lane owns a 4 x 4 patch of pixels IN REGISTERS (16 stamps + 16 bases);
+//   * a wave is a 256-pixel-wide band (64 lanes x 4 columns); the left/right neighbour columns come
+//     from the adjacent LANES with one DPP wave shift each (v_mov_b32_dpp wave_shr:1 / wave_shl:1;
+//     the `old` operand supplies the tile's halo column for lane 0 / lane 63): no LDS, no conflicts;
+//   * the NW waves of a workgroup are NW bands stacked vertically: tile = 256 x 4*NW pixels; only
+//     band boundary rows go through LDS, one ds_write_b128 / ds_read_b128 per lane and row;
+//   * global loads/stores are 16 B per lane, 1 KiB per wave instruction, row contiguous, and every
+//     load is unconditional on a clamped address (a load under a data-dependent branch is waited
+//     for before the next is issued -- that serialised ~50 round trips per thread in the first
+//     version of this engine);
+//   * one iteration = four sweeps (down, right, up, left); a sweep updates a whole patch row (or
+//     column) at a time, i.e. 4 independent pixel updates, so dependency chains are 4 long.
+//
+// What the measurements said (tools/diag_relax.hip, per-workgroup s_memrealtime stamps, MI355X):
+// with ~5 global atomics per tile on shared words (statistics + convergence counters) a full pass
+// took 440 us however the sweeps were organised: same-address atomics retire at ~12 ns each, and
+// 8192 tiles x 4-5 of them IS 440 us.  Hence: no same-address atomic on the tile path.  Convergence
+// words are plain stores of 1 into striped slots (idempotent), statistics are striped counters
+// that exist only when profiling is on.
+#include "ws_common.hpp"
+
+namespace wsk {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// Diagnostic build only (tools/diag_relax.hip defines WS_DIAG_STAMPS): per-workgroup phase stamps.
+#ifdef WS_DIAG_STAMPS
+__device__ unsigned long long *g_diag = nullptr;
+#define WS_STAMP(slot)                                                                          \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define WS_STAMP(slot) do {} while (0)
+#endif
+
+constexpr int RX_TW = 256;   // tile width: 64 lanes x 4 columns
+constexpr int RX_P = 4;      // patch side
+
+__device__ __forceinline__ uint32_t lane_left(uint32_t old, uint32_t v) {     // lane i <- lane i-1, lane 0 keeps old
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_right(uint32_t old, uint32_t v) {    // lane i <- lane i+1, lane 63 keeps old
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xF, 0xF, false);
+}
+
+// one pixel: key <- min(key, max(base, 1 + min4)).  The kernel keeps b <= t for every pixel (pixels
+// that can never change -- seeds, the image border, halo copies -- carry b = t), and under b <= t
+// min(t, max(b, x)) is the median of (b, x, t): v_min_u32, v_min3_u32, v_add_u32, v_med3_u32.
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
+  return max(min(a, b), min(max(a, b), c));
+}
+__device__ __forceinline__ bool relax_px(uint32_t &t, uint32_t b, uint32_t u, uint32_t d, uint32_t l, uint32_t r) {
+  const uint32_t n = med3u(b, min(min(u, d), min(l, r)) + 1u, t);
+  const bool lower = n != t;     // v_cmp + a scalar OR: the flag lives in an SGPR pair
+  t = n;
+  return lower;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
+                                                      int H, int W, int tilesX, int tilesY, uint32_t max_level,
+                                                      uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
+                                                      const uint32_t *__restrict__ seed_labels) {
+  constexpr int TH = NW * RX_P;
+  // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
+  __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NW + 2][RX_TW];
+  // the tile border as loaded (top row, bottom row, left column, right column): compared with the
+  // final values to tell which tile edges changed; parked in LDS to keep the VGPR count at 80
+  __shared__ __attribute__((aligned(16))) uint32_t sInitRow[2][RX_TW];
+  __shared__ uint32_t sInitCol[2][TH];
+  __shared__ uint32_t s_edges;
+  // "some lane changed in iteration k" lives in slot k % 3: written before barrier k, read after it,
+  // cleared by thread 0 for iteration k + 2 -- one barrier per iteration instead of the three a
+  // __syncthreads_or costs
+  __shared__ uint32_t s_flag[3];
+
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const size_t ntiles = (size_t)tilesX * tilesY;
+  const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
+  uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
+  // the first wave of workgroup 0 clears the next pass's convergence slot
+  if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
+    pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
+  if (pass != 0) {
+    // did a neighbour change the edge it shares with this tile in the previous pass?  Four
+    // independent loads on clamped indices, one decision.
+    const int t = tile_y * tilesX + tile_x;
+    const uint32_t su = stamps_prev[(size_t)(tile_y > 0 ? t - tilesX : t) * 4 + 1];
+    const uint32_t sd = stamps_prev[(size_t)(tile_y + 1 < tilesY ? t + tilesX : t) * 4 + 0];
+    const uint32_t sl = stamps_prev[(size_t)(tile_x > 0 ? t - 1 : t) * 4 + 3];
+    const uint32_t sr = stamps_prev[(size_t)(tile_x + 1 < tilesX ? t + 1 : t) * 4 + 2];
+    const bool run = (tile_y > 0 && su == pass) | (tile_y + 1 < tilesY && sd == pass) | (tile_x > 0 && sl == pass) |
+                     (tile_x + 1 < tilesX && sr == pass);
+    if (!run) return;
+  }
+
+  WS_STAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, band = tid >> 6;
+  const int x0 = tile_x * RX_TW, y0 = tile_y * TH;
+  const int gx0 = x0 + lane * RX_P, gyb = y0 + band * RX_P;
+  if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+
+  // ---- load phase ---------------------------------------------------------------------------
+  uint32_t T[RX_P][RX_P], B[RX_P][RX_P], halo[RX_P];
+  // fast path (workgroup uniform): the tile lies inside the image in x and image rows can be read
+  // as aligned dwords -> one 16-byte stamp load and one 4-byte image load per lane and row
+  const bool fast = (x0 + RX_TW <= W) && ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
+  // tile halo columns: lanes 0..31 fetch the column left of the tile, lanes 32..63 the one right of
+  // it; only lane 0 / lane 63 ever use the value (as the DPP `old` operand)
+  const int xh = lane < 32 ? (x0 > 0 ? x0 - 1 : 0) : (x0 + RX_TW < W ? x0 + RX_TW : W - 1);
+  const bool xh_ok = lane < 32 ? x0 > 0 : x0 + RX_TW < W;
+  const int gy_halo_raw = band == 0 ? y0 - 1 : y0 + TH;
+  const int gy_halo = min(max(gy_halo_raw, 0), H - 1);
+  u32x4_t halo_row;
+  // pass 0 of a whole-image transform reads the freshly painted LABEL plane instead of a stamp
+  // plane (seed = coloured pixel = stamp 0, everything else never-coloured): nobody has to fill the
+  // stamp plane first, this pass writes all of it
+  const bool from_labels = seed_labels != nullptr;
+  const uint32_t *ksrc = from_labels ? seed_labels : keys;
+  if (fast) {
+    u32x4_t kv[RX_P];
+    uint32_t iv[RX_P];
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const int gyc = min(gyb + r, H - 1);
+      kv[r] = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gyc * W + gx0);
+      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gx0);
+      halo[r] = ksrc[(size_t)gyc * W + xh];
+    }
+    halo_row = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gy_halo * W + gx0);
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      T[r][0] = kv[r].x; T[r][1] = kv[r].y; T[r][2] = kv[r].z; T[r][3] = kv[r].w;
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) B[r][c] = (iv[r] >> (8 * c)) & 0xFFu;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const int gyc = min(gyb + r, H - 1);
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) {
+        const int gxc = min(gx0 + c, W - 1);
+        T[r][c] = ksrc[(size_t)gyc * W + gxc];
+        B[r][c] = img[(size_t)gyc * img_stride + gxc];
+      }
+      halo[r] = ksrc[(size_t)gyc * W + xh];
+    }
+    halo_row.x = ksrc[(size_t)gy_halo * W + min(gx0 + 0, W - 1)];
+    halo_row.y = ksrc[(size_t)gy_halo * W + min(gx0 + 1, W - 1)];
+    halo_row.z = ksrc[(size_t)gy_halo * W + min(gx0 + 2, W - 1)];
+    halo_row.w = ksrc[(size_t)gy_halo * W + min(gx0 + 3, W - 1)];
+  }
+  if (from_labels) {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) T[r][c] = T[r][c] ? 0u : KEY_INF;
+      halo[r] = halo[r] ? 0u : KEY_INF;
+    }
+    halo_row.x = halo_row.x ? 0u : KEY_INF; halo_row.y = halo_row.y ? 0u : KEY_INF;
+    halo_row.z = halo_row.z ? 0u : KEY_INF; halo_row.w = halo_row.w ? 0u : KEY_INF;
+  }
+#pragma unroll
+  for (int r = 0; r < RX_P; ++r) {
+    const int gy = gyb + r;
+    const bool row_ok = gy < H, row_int = gy >= 1 && gy < H - 1;
+#pragma unroll
+    for (int c = 0; c < RX_P; ++c) {
+      const int gx = gx0 + c;
+      if (!(row_ok && gx < W)) T[r][c] = KEY_INF;
+      // bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224);
+      // everything else, and every seed (stamp 0 < base), is pinned at its current stamp: b = t
+      const uint32_t v = B[r][c];
+      const uint32_t base = (row_int && gx >= 1 && gx < W - 1 && v <= max_level) ? ((v << 24) | 1u) : KEY_INF;
+      B[r][c] = min(base, T[r][c]);
+    }
+    if (!(row_ok && xh_ok)) halo[r] = KEY_INF;
+  }
+  {
+    const bool ok = gy_halo_raw >= 0 && gy_halo_raw < H;
+    if (!(ok && gx0 + 0 < W)) halo_row.x = KEY_INF;
+    if (!(ok && gx0 + 1 < W)) halo_row.y = KEY_INF;
+    if (!(ok && gx0 + 2 < W)) halo_row.z = KEY_INF;
+    if (!(ok && gx0 + 3 < W)) halo_row.w = KEY_INF;
+    if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][lane * RX_P]) = halo_row;
+    if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NW + 1][lane * RX_P]) = halo_row;
+    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+  }
+  if (band == 0) *reinterpret_cast<u32x4_t *>(&sInitRow[0][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+  if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sInitRow[1][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+  if (lane == 0 || lane == 63) {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] = T[r][lane == 0 ? 0 : 3];
+  }
+  __syncthreads();
+  WS_STAMP(1);
+
+  // ---- relaxation ---------------------------------------------------------------------------
+  bool any_lower = from_labels;      // a pass that creates the stamp plane writes every patch
+  uint32_t iters = 0;
+  for (; max_iters != 0;) {
+    ++iters;
+    bool changed = false;
+    const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
+    const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
+    const uint32_t up[RX_P] = {up4.x, up4.y, up4.z, up4.w};
+    const uint32_t dn[RX_P] = {dn4.x, dn4.y, dn4.z, dn4.w};
+    uint32_t L[RX_P], R[RX_P];
+
+    // sweep down: rows top to bottom, the 4 pixels of a row are independent
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
+      const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c)
+        changed |= relax_px(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c]);
+    }
+    // sweep right: columns left to right
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
+#pragma unroll
+    for (int c = 0; c < RX_P; ++c) {
+      const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
+      const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r)
+        changed |= relax_px(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1]);
+    }
+    // sweep up: rows bottom to top
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
+#pragma unroll
+    for (int r = RX_P - 1; r >= 0; --r) {
+      const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
+      const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c)
+        changed |= relax_px(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c]);
+    }
+    // sweep left: columns right to left
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
+#pragma unroll
+    for (int c = RX_P - 1; c >= 0; --c) {
+      const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
+      const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r)
+        changed |= relax_px(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1]);
+    }
+    any_lower |= changed;
+    // publish this band's boundary rows for the bands above / below
+    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+    const uint32_t slot = (iters - 1) % 3;
+    if (__builtin_amdgcn_ballot_w64(changed) != 0 && lane == 0) s_flag[slot] = 1;
+    __syncthreads();
+    const bool again = s_flag[slot] != 0;
+    if (tid == 0) s_flag[(slot + 2) % 3] = 0;
+    if (!again || iters >= max_iters) break;
+  }
+  WS_STAMP(2);
+#ifdef WS_DIAG_STAMPS
+  if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = iters;
+#endif
+
+  // ---- write back the patches that changed (16 B per lane and row), ring-carry check, edge flags
+  uint32_t e = 0, ovf = 0;
+  if (any_lower) {
+    const bool full_x = gx0 + RX_P <= W;
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const int gy = gyb + r;
+      if (gy < H) {
+        if (full_x) {
+          *reinterpret_cast<u32x4_t *>(keys + (size_t)gy * W + gx0) = u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < RX_P; ++c) if (gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c)   // a finite non-seed stamp with ring 0 can only come from a carry out of the ring field
+        ovf |= (T[r][c] != 0u && T[r][c] < KEY_INF && (T[r][c] & RING_MASK) == 0u);
+    }
+    e |= 16u;
+    if (band == 0) {
+      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][lane * RX_P]);
+      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= 1u;
+    }
+    if (band == NW - 1) {
+      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][lane * RX_P]);
+      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= 2u;
+    }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r)
+        if (sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] != T[r][lane == 0 ? 0 : 3]) e |= lane == 0 ? 4u : 8u;
+    }
+  }
+  if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
+  if (e) atomicOr(&s_edges, e);
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t ed = s_edges;
+    const uint32_t stripe = (blockIdx.x % NSTRIPE) * STRIPE_STRIDE;
+    if (ed) {
+      const size_t t = (size_t)tile_y * tilesX + tile_x;
+      if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
+      if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
+      if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
+      if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
+      // plain, idempotent stores into striped words: no same-address atomics on the tile path
+      if (ed & 15u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
+      pf.any_change[stripe] = 1u;
+    }
+    if (pf.stats) {            // profiling only: striped counters, one per 64-byte line
+      atomicAdd(&pf.stats[stripe], 1u);
+      atomicAdd(&pf.stats[FLAG_SLOT + stripe], iters);
+    }
+  }
+  WS_STAMP(3);
+}
+
+constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
+
+size_t relax_tiles(int h, int w) {
+  const int th = RX_NW * RX_P;
+  return (size_t)((w + RX_TW - 1) / RX_TW) * ((h + th - 1) / th);
+}
+
+hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
+                      uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
+                      const uint32_t *seed_labels) {
+  const int th = RX_NW * RX_P;
+  const int tx = (w + RX_TW - 1) / RX_TW, ty = (h + th - 1) / th;
+  k_relax<RX_NW><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, max_level, pass, stamps, pf, max_iters,
+                                                pass == 0 ? seed_labels : nullptr);
+  return hipGetLastError();
+}
+
+}  // namespace wsk
