@@ -43,9 +43,11 @@ struct ws_ctx {
   ws_stats stats{};
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
-  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes;
+  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs;
   uint32_t *pinned = nullptr;      // COUNTER_RING + 4 words of pinned host memory
-  hipEvent_t ring_ev[COUNTER_RING]{};
+  hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
+  hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
+  hipStream_t copy_stream = nullptr;    // carries the per-pass flag read-backs
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -64,7 +66,8 @@ namespace {
 constexpr int FLAG_EDGE = 0;                                 // [COUNTER_RING][FLAG_SLOT] striped "a tile edge changed"
 constexpr int FLAG_ANY = COUNTER_RING * FLAG_SLOT;           // [FLAG_SLOT] striped "any pixel changed"
 constexpr int FLAG_STATS = FLAG_ANY + FLAG_SLOT;             // [2][FLAG_SLOT] striped tile / sweep counters (profiling)
-constexpr int FLAG_MISC = FLAG_STATS + 2 * FLAG_SLOT;
+constexpr int FLAG_REFS = FLAG_STATS + 2 * FLAG_SLOT;        // [FLAG_SLOT] striped lengths of the reference work lists
+constexpr int FLAG_MISC = FLAG_REFS + FLAG_SLOT;
 constexpr int FLAG_OVERFLOW = FLAG_MISC + 0;
 constexpr int FLAG_SEED_ERR = FLAG_MISC + 1;
 constexpr int FLAG_TOTAL = FLAG_MISC + 2;                    // minima total
@@ -189,15 +192,20 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   for (;; ++pass) {
     HIP_TRY(c, launch(pass));
     const int slot = pass % COUNTER_RING;
+    // the flag read-back rides a side stream: the next pass never queues behind a copy
+    HIP_TRY(c, hipEventRecord(c->kern_ev[slot], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[slot], 0));
     HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_EDGE + slot * FLAG_SLOT], d_flags + FLAG_EDGE + slot * FLAG_SLOT,
-                              FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
+                              FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->copy_stream));
     if (pass >= PASS_LOOKAHEAD) {
       const int prev = (pass - PASS_LOOKAHEAD) % COUNTER_RING;
       HIP_TRY(c, hipEventSynchronize(c->ring_ev[prev]));
       if (!slot_nonzero(&c->pinned[FLAG_EDGE + prev * FLAG_SLOT])) break;
     }
   }
+  // later work on the main stream may reuse the flag words: order it after the last read-back
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring_ev[pass % COUNTER_RING], 0));
   *passes_out = pass + 1;
   return WS_OK;
 }
@@ -232,15 +240,11 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
 
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
-  if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
-
+  // no host round trip here: the error words are read once, after the resolve launches are queued
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw));
+    if ((rc = ensure(c, c->refs, NSTRIPE * resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p));
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
@@ -250,6 +254,8 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
     if (rc) return rc;
   }
   c->stats.launches_resolve = c->stats.resolve_passes;
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, c->stream));
   if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
     HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_STATS], flags + FLAG_STATS, 2 * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -257,7 +263,11 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
       c->stats.tiles_run_relax += c->pinned[FLAG_STATS + i * STRIPE_STRIDE];
       c->stats.relax_tile_iterations += c->pinned[FLAG_STATS + FLAG_SLOT + i * STRIPE_STRIDE];
     }
+  } else {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
   c->have_keys = true;
   c->last_h = ph;
   c->last_w = pw;
@@ -468,6 +478,8 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->kern_ev[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && ensure(c, c->flags, FLAG_WORDS * sizeof(uint32_t)) == WS_OK;
   if (!ok) { ws_ctx_destroy(c); return WS_ERR_HIP; }
   *out = c;
@@ -482,11 +494,13 @@ void ws_ctx_destroy(ws_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux,
-                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes})
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < COUNTER_RING; ++i) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
+  for (int i = 0; i < COUNTER_RING; ++i) if (c->kern_ev[i]) (void)hipEventDestroy(c->kern_ev[i]);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

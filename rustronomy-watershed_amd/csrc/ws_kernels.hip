@@ -325,12 +325,12 @@ constexpr uint32_t REF_BIT = 0x80000000u;
 typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
-                                                            int H, int W, int tilesX) {
-  // stamps of the tile and its 1-px halo ring, later overwritten by the parent pointers
+                                                            int H, int W, int tilesX, uint32_t *ref_count,
+                                                            uint32_t *ref_list, size_t ref_cap) {
+  // One 66 x 66 LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[LP * LP];
-  // colours of the tile's own pixels as painted (seeds), so a root's colour is an LDS read
-  __shared__ __attribute__((aligned(16))) uint32_t sL[TS * TS];
   __shared__ uint32_t s_flag[3];
+  __shared__ uint32_t s_wave_refs[NTHREADS / 64], s_ref_base;
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, strip = tid >> 6;
@@ -339,79 +339,76 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
   const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
   if (tid < 3) s_flag[tid] = 0;
 
-  // ---- loads: unconditional on clamped addresses (see ws_relax.hip), 16 B per lane where the
-  // tile lies inside the image in x and rows are 16-byte aligned
-  const bool fast = (x0 + TS <= W) && (W & 3) == 0;
-  if (fast) {
-    u32x4_r kv[4], lv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                       // 1024 chunks of 4 px: row = id / 16, chunk = id % 16
-      const int id = tid + k * NTHREADS, r = id >> 4, cx = (id & 15) * 4;
-      const size_t g = (size_t)min(y0 + r, H - 1) * W + x0 + cx;
-      kv[k] = *reinterpret_cast<const u32x4_r *>(keys + g);
-      lv[k] = *reinterpret_cast<const u32x4_r *>(labels + g);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int id = tid + k * NTHREADS, r = id >> 4, cx = (id & 15) * 4;
-      const bool ok = y0 + r < H;
-      uint32_t *d = &sB[(r + 1) * LP + cx + 1];
-      d[0] = ok ? kv[k].x : KEY_INF; d[1] = ok ? kv[k].y : KEY_INF; d[2] = ok ? kv[k].z : KEY_INF; d[3] = ok ? kv[k].w : KEY_INF;
-      *reinterpret_cast<u32x4_r *>(&sL[r * TS + cx]) = lv[k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {                   // 4096 pixels, 16 per thread, row contiguous across lanes
-      const int id = tid + k * NTHREADS, r = id >> 6, cxx = id & 63;
-      const int gyy = y0 + r, gxx = x0 + cxx;
-      const size_t g = (size_t)min(gyy, H - 1) * W + min(gxx, W - 1);
-      const uint32_t kvv = keys[g], lvv = labels[g];
-      const bool ok = gyy < H && gxx < W;
-      sB[(r + 1) * LP + cxx + 1] = ok ? kvv : KEY_INF;
-      sL[r * TS + cxx] = ok ? lvv : 0u;
-    }
-  }
+  // ---- loads: unconditional on clamped addresses (see ws_relax.hip).  Every thread owns the column
+  // strip (gx, gy0 .. gy0+15): stamps and painted colours of the strip stay in registers, rows are
+  // 256 B contiguous across the wave.
+  uint32_t K[STRIP], Lb[STRIP];
   {
-    // halo ring: thread t < 64 loads (top, bottom, left, right)[t]
-    const int side = tid >> 6, t = tid & 63;            // 4 sides x 64 positions = 256 threads
+    const int gxc = min(gx, W - 1);
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) {
+      const size_t g = (size_t)min(gy0 + i, H - 1) * W + gxc;
+      K[i] = keys[g];
+      Lb[i] = labels[g];
+    }
+    // halo ring: thread t loads (top, bottom, left, right)[t & 63]
+    const int side = tid >> 6, t = tid & 63;
     const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
     const int hx = side == 2 ? x0 - 1 : (side == 3 ? x0 + TS : x0 + t);
-    const uint32_t v = keys[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
-    const bool ok = hy >= 0 && hy < H && hx >= 0 && hx < W;
-    const int ly = hy - (y0 - 1), lxx = hx - (x0 - 1);
-    sB[ly * LP + lxx] = ok ? v : KEY_INF;
-  }
-  if (tid < 4) sB[(tid & 1 ? LP - 1 : 0) * LP + (tid & 2 ? LP - 1 : 0)] = KEY_INF;   // corners: never a parent
-  __syncthreads();
-
-  uint32_t P[STRIP];
+    const uint32_t hv = keys[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
+    const bool hok = hy >= 0 && hy < H && hx >= 0 && hx < W;
 #pragma unroll
-  for (int i = 0; i < STRIP; ++i) {
-    const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
-    const uint32_t k = sB[cell];
-    const int gy = gy0 + i;
-    uint32_t p = cell;
-    // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U (lib.rs:190, 245)
-    if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
-      const uint32_t d = sB[cell + LP], r = sB[cell + 1], l = sB[cell - 1];
-      p = d < k ? cell + LP : (r < k ? cell + 1 : (l < k ? cell - 1 : cell - LP));
+    for (int i = 0; i < STRIP; ++i) {
+      if (!(gy0 + i < H && gx < W)) { K[i] = KEY_INF; Lb[i] = 0u; }
+      sB[(ly0 + i) * LP + lx] = K[i];
     }
-    P[i] = p;
+    sB[(hy - (y0 - 1)) * LP + (hx - (x0 - 1))] = hok ? hv : KEY_INF;
   }
   __syncthreads();
-  for (int idx = tid; idx < LP * LP; idx += NTHREADS) sB[idx] = (uint32_t)idx;     // halo cells are roots
-  __syncthreads();
+
+  // ---- parent pointer of every pixel of the strip: up/down neighbours are registers of this thread
+  uint32_t P[STRIP];
+  {
+    const uint32_t k_above = sB[(ly0 - 1) * LP + lx], k_below = sB[(ly0 + STRIP) * LP + lx];
 #pragma unroll
-  for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = P[i];
+    for (int i = 0; i < STRIP; ++i) {
+      const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
+      const uint32_t k = K[i];
+      const int gy = gy0 + i;
+      uint32_t p = cell;
+      // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U (lib.rs:190, 245)
+      if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
+        const uint32_t d = i == STRIP - 1 ? k_below : K[i + 1];
+        const uint32_t r = sB[cell + 1], l = sB[cell - 1];
+        (void)k_above;      // "up" is the fall-through: at a fixpoint one of the four is earlier
+        p = d < k ? cell + LP : (r < k ? cell + 1 : (l < k ? cell - 1 : cell - LP));
+      }
+      P[i] = p;
+    }
+  }
+  __syncthreads();                               // every stamp has been read: the tile becomes pointers
+  {
+    const int side = tid >> 6, t = tid & 63;     // halo cells are roots (self pointers)
+    const int ly = side == 0 ? 0 : (side == 1 ? LP - 1 : t + 1), lxx = side == 2 ? 0 : (side == 3 ? LP - 1 : t + 1);
+    sB[ly * LP + lxx] = (uint32_t)(ly * LP + lxx);
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = P[i];
+  }
   __syncthreads();
 
-  for (uint32_t it = 0;; ++it) {               // pointer jumping: P <- P(P)
+  uint32_t live = 0;                             // pixels whose pointer may still move
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) live |= (P[i] != (uint32_t)((ly0 + i) * LP + lx)) ? (1u << i) : 0u;
+  for (uint32_t it = 0;; ++it) {                 // pointer jumping: P <- P(P)
     bool changed = false;
 #pragma unroll
     for (int i = 0; i < STRIP; ++i) {
-      const uint32_t q = P[i];
-      const uint32_t g = sB[q];
-      if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = true; }
+      if ((live >> i) & 1u) {
+        const uint32_t q = P[i];
+        const uint32_t g = sB[q];
+        if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = true; }
+        else live &= ~(1u << i);                 // q is a root: this pixel is done
+      }
     }
     // one barrier per round: flag slot it % 3 (see k_relax)
     const uint32_t slot = it % 3;
@@ -421,7 +418,13 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
     if (!again) break;
   }
+  // every pointer is final and in registers: the tile now becomes the painted colours, so that the
+  // colour of an in-tile root (a seed) is one LDS read
+#pragma unroll
+  for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = Lb[i];
+  __syncthreads();
 
+  uint32_t refmask = 0;                          // pixels whose chain leaves the tile
   if (gx < W) {
 #pragma unroll
     for (int i = 0; i < STRIP; ++i) {
@@ -432,35 +435,69 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
         const int rly = (int)(r / LP), rlx = (int)(r - (uint32_t)rly * LP);
         const bool inside = rly >= 1 && rly <= TS && rlx >= 1 && rlx <= TS;
         const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - 1 + rlx);
-        labels[(size_t)gy * W + gx] = inside ? sL[(rly - 1) * TS + (rlx - 1)] : (REF_BIT | (uint32_t)rg);
+        labels[(size_t)gy * W + gx] = inside ? sB[r] : (REF_BIT | (uint32_t)rg);
+        if (!inside) refmask |= 1u << i;
       }
     }
   }
-}
-
-__global__ void k_resolve_chase(uint32_t *labels, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) {
-    uint32_t v = labels[i];
-    if (v & REF_BIT) {
-      // bounded: a chain visits strictly decreasing stamps, so it is shorter than the pixel count
-      for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
-        v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      labels[i] = v;
-    }
+  // work list of the reference pixels for k_resolve_chase: one striped reservation per workgroup
+  // (workgroups of one stripe share a counter: ntiles / NSTRIPE adds per address, not ntiles)
+  const uint32_t cnt = __popc(refmask);
+  uint32_t incl = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wave_refs[strip] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < NTHREADS / 64; ++k) total += s_wave_refs[k];
+    s_ref_base = total ? atomicAdd(&ref_count[(blockIdx.x % NSTRIPE) * STRIPE_STRIDE], total) : 0u;
+  }
+  __syncthreads();
+  if (refmask) {
+    uint32_t pos = s_ref_base + incl - cnt;
+    for (int k = 0; k < strip; ++k) pos += s_wave_refs[k];
+    uint32_t *dst = ref_list + (size_t)(blockIdx.x % NSTRIPE) * ref_cap;
+#pragma unroll
+    for (int i = 0; i < STRIP; ++i)
+      if ((refmask >> i) & 1u) dst[pos++] = (uint32_t)((size_t)(gy0 + i) * W + gx);
   }
 }
 
-hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w) {
+// blockIdx.y = stripe of the work list; a reference always points to a pixel with a strictly smaller
+// stamp, so chains end at a seed; a racing reader sees either the reference or what it resolves to
+__global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
+                                const uint32_t *__restrict__ ref_list, size_t ref_cap, size_t n) {
+  const uint32_t count = ref_count[blockIdx.y * STRIPE_STRIDE];
+  const uint32_t *list = ref_list + (size_t)blockIdx.y * ref_cap;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
+    const uint32_t i = list[j];
+    uint32_t v = labels[i];
+    for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
+      v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    labels[i] = v;
+  }
+}
+
+size_t resolve_ref_capacity(int h, int w) {
+  const size_t ntiles = (size_t)tiles_of(w) * tiles_of(h);
+  return ((ntiles + NSTRIPE - 1) / NSTRIPE) * (size_t)(TS * TS);    // per stripe: its workgroups x pixels per tile
+}
+
+hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
+                              uint32_t *ref_count, uint32_t *ref_list) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
-  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx);
-  hipError_t e = hipGetLastError();
+  const size_t cap = resolve_ref_capacity(h, w);
+  hipError_t e = hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
-  const int blocks = (int)((n + 1023) / 1024 < 16384 ? (n + 1023) / 1024 : 16384);
-  k_resolve_chase<<<blocks, 256, 0, s>>>(labels, n);
+  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  k_resolve_chase<<<dim3(32, NSTRIPE), 256, 0, s>>>(labels, ref_count, ref_list, cap, n);
   return hipGetLastError();
 }
 
