@@ -115,8 +115,9 @@ def main():
         if args.engine == "fused":
             kname, k_ms, k_launches = "k_relax", agg["ms_relax"], agg["launches_relax"]
             tile_px = 256 * 32
-            # per tile that runs: image 1 B + stamp read 4 B + stamp write 4 B per pixel
-            k_bytes = agg["tiles_run_relax"] * tile_px * 9
+            # every tile that runs reads its image (1 B) and stamps (4 B) once per pixel; every stamp is
+            # written once by the pass that creates the plane (later passes rewrite only what changed)
+            k_bytes = agg["tiles_run_relax"] * tile_px * 5 + args.steps * npx * 4
         else:
             kname, k_ms, k_launches = "k_flood_step", agg["ms_sweep"], agg["launches_sweep"]
             k_bytes = agg["launches_sweep"] * npx * (1 + 4 + 4)
@@ -143,8 +144,8 @@ def main():
                 "tiles_run_per_step": round(agg["tiles_run_relax"] / args.steps, 1),
                 "tile_sweep_iterations_per_step": round(agg["relax_tile_iterations"] / args.steps, 1),
                 "algorithmic_bytes_per_launch": int(k_bytes_per_launch),
-                "note": "algorithmic bytes of THIS kernel: 9 B per pixel (1 image + 4 stamp read + 4 stamp write) of every "
-                        "256x32 tile that runs, counted on the device -- see DESIGN.md section 5",
+                "note": "algorithmic bytes of THIS kernel: 5 B per pixel (1 image + 4 stamp) read by every 256x32 tile "
+                        "that runs (counted on the device) + 4 B per pixel written once -- see DESIGN.md section 5",
                 # the figure BASELINE.md's 30 % target is phrased in: bytes a 255-sweep engine would move
                 "sweep_model": {"bytes_per_transform": int(b_sweep), "equivalent_GBps": round(sweep_equiv, 1),
                                 "frac_of_peak": round(sweep_equiv / HBM_PEAK_GBS, 4),
@@ -152,6 +153,11 @@ def main():
                 "device_ms_per_step": {k: round(agg[k] / args.steps, 4) for k in ("ms_total", "ms_relax", "ms_resolve", "ms_sweep", "ms_other")},
             },
         }
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if args.engine == "fused" and H == 8192 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            out["roofline"]["traffic"] = int(tj["k_relax"]["bytes_per_launch"])
+            out["roofline"]["traffic_source"] = tj["source"]
         if world == 1 and args.cpu_size > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1)
         else:

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are collected in separate
 runs: MI355X_MICROARCH.md, rocprofv3 PMC slots).  Runs, on one 8192x8192 field:
-  1. a calibration kernel with the same access width as the engine's planes (4 B per lane reads of
-     coalesced rows): a few steps of the sweep engine's k_flood_step, which reads the u8 image and
-     the u32 label plane once (5N bytes; neighbour rows are cache hits) and writes 4N bytes;
+  1. two calibration kernels of known size, one per access width the engine uses: a few steps of the
+     sweep engine's k_flood_step (4 B per lane: reads the u8 image and the u32 label plane once,
+     5N bytes, writes 4N) and one device-to-device copy of the stamp plane (16 B per lane: 4N bytes
+     in, 4N bytes out);
   2. `steps` segmenting transforms through the C ABI.
 tools/pmc_summarise.py turns the two counter CSVs into per-kernel bytes per launch."""
 import argparse
@@ -33,7 +34,9 @@ def main():
     seeds = eng.find_local_minima(img)
     labels = torch.empty((n, n), dtype=torch.int32, device=eng.device)
     pkg = sys.modules["rustronomy_watershed_amd"]
-    eng.segment(img, seeds, max_level=1, engine=pkg.ENGINE_SWEEP, out=labels)   # calibration launches
+    eng.segment(img, seeds, max_level=1, engine=pkg.ENGINE_SWEEP, out=labels)   # calibration launches (4 B/lane)
+    eng.segment(img, seeds, out=labels)
+    keys_copy = eng.last_arrival()      # calibration: one 4N-byte device-to-device copy with 16 B/lane accesses
     torch.cuda.synchronize()
     for _ in range(args.steps):
         if args.merge:

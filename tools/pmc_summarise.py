@@ -16,13 +16,15 @@ import sys
 def per_kernel(path, counter):
     tot = collections.defaultdict(float)
     cnt = collections.defaultdict(set)
+    big = collections.defaultdict(float)
     for row in csv.DictReader(open(path)):
         if row.get("Counter_Name") != counter:
             continue
         name = row["Kernel_Name"].split("(")[0]
         tot[name] += float(row["Counter_Value"])
         cnt[name].add(row["Dispatch_Id"])
-    return {k: (tot[k], len(cnt[k])) for k in tot}
+        big[name] = max(big[name], float(row["Counter_Value"]))
+    return {k: (tot[k], len(cnt[k]), big[k]) for k in tot}
 
 
 def main():
@@ -30,22 +32,30 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     n_words = int(sys.argv[3])
     cal_name = next((k for k in fetch if "k_flood_step" in k), None)
-    scale = 1.0
-    cal = None
+    scale4 = scale16 = 1.0
+    cal = {}
     if cal_name:
         raw = fetch[cal_name][0] / fetch[cal_name][1] * 1024
-        scale = (5.0 * n_words) / raw if raw else 1.0
-        wraw = write.get(cal_name, (0, 1))
-        cal = {"kernel": cal_name, "true_read_bytes": 5 * n_words, "FETCH_SIZE_bytes_raw": raw, "read_scale": scale,
-               "WRITE_SIZE_bytes_raw": wraw[0] / max(wraw[1], 1) * 1024, "true_write_bytes": 4 * n_words}
+        scale4 = (5.0 * n_words) / raw if raw else 1.0
+        wraw = write.get(cal_name, (0, 1, 0))
+        cal["4B_per_lane"] = {"kernel": cal_name, "true_read_bytes": 5 * n_words, "FETCH_SIZE_bytes_raw": raw, "read_scale": scale4,
+                              "WRITE_SIZE_bytes_raw": wraw[0] / max(wraw[1], 1) * 1024, "true_write_bytes": 4 * n_words}
+    copy_name = next((k for k in fetch if "copyBuffer" in k), None)
+    if copy_name and fetch[copy_name][2] * 1024 > n_words:      # the one plane-sized copy (largest dispatch)
+        raw = fetch[copy_name][2] * 1024
+        scale16 = (4.0 * n_words) / raw
+        cal["16B_per_lane"] = {"kernel": copy_name + " (largest dispatch)", "true_read_bytes": 4 * n_words,
+                               "FETCH_SIZE_bytes_raw": raw, "read_scale": scale16,
+                               "WRITE_SIZE_bytes_raw": write.get(copy_name, (0, 1, 0))[2] * 1024, "true_write_bytes": 4 * n_words}
     out = {"calibration": cal, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
-        f, fn = fetch.get(k, (0.0, 0))
-        w, wn = write.get(k, (0.0, 0))
+        f, fn, _ = fetch.get(k, (0.0, 0, 0.0))
+        w, wn, _ = write.get(k, (0.0, 0, 0.0))
         out["kernels"][k] = {
             "launches": max(fn, wn),
             "fetch_bytes_per_launch_raw": f / max(fn, 1) * 1024,
-            "fetch_bytes_per_launch_calibrated": f / max(fn, 1) * 1024 * scale,
+            "fetch_bytes_per_launch_scaled_4B": f / max(fn, 1) * 1024 * scale4,
+            "fetch_bytes_per_launch_scaled_16B": f / max(fn, 1) * 1024 * scale16,
             "write_bytes_per_launch": w / max(wn, 1) * 1024,
         }
     json.dump(out, sys.stdout, indent=1)
