@@ -507,29 +507,70 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
 // uncoloured and has a coloured 4-neighbour takes the first coloured neighbour in
 // down,right,left,up order; reads only the previous plane (lin), writes the next (lout).
 
+// first coloured neighbour in down, right, left, up order (lib.rs:190, 237-248 with col0)
+__device__ __forceinline__ uint32_t pick_drlu(uint32_t d, uint32_t r, uint32_t l, uint32_t u) {
+  return d ? d : (r ? r : (l ? l : u));
+}
+
+// scalar form: any width / alignment.  All loads unconditional on clamped addresses; the "something
+// was coloured" word is a plain idempotent store (one shared atomic per workgroup would serialise).
 __global__ __launch_bounds__(256) void k_flood_step(const uint8_t *__restrict__ img, size_t img_stride,
                                                     const uint32_t *__restrict__ lin, uint32_t *__restrict__ lout,
                                                     int H, int W, uint32_t level, uint32_t *counter) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  int coloured = 0;
-  if (x < W && y < H) {
-    const size_t p = (size_t)y * W + x;
-    uint32_t v = lin[p];
-    if (v == 0u && y >= 1 && y < H - 1 && x >= 1 && x < W - 1 && img[(size_t)y * img_stride + x] <= level) {
-      const uint32_t d = lin[p + W], r = lin[p + 1], l = lin[p - 1], u = lin[p - W];
-      v = d ? d : (r ? r : (l ? l : u));
-      coloured = v != 0u;
-    }
-    lout[p] = v;
+  const int xc = min(x, W - 1), yc = min(y, H - 1);
+  const int xm = max(xc - 1, 0), xp = min(xc + 1, W - 1), ym = max(yc - 1, 0), yp = min(yc + 1, H - 1);
+  const uint32_t c = lin[(size_t)yc * W + xc];
+  const uint32_t d = lin[(size_t)yp * W + xc], r = lin[(size_t)yc * W + xp];
+  const uint32_t l = lin[(size_t)yc * W + xm], u = lin[(size_t)ym * W + xc];
+  const uint32_t v = img[(size_t)yc * img_stride + xc];
+  const bool floodable = c == 0u && y >= 1 && y < H - 1 && x >= 1 && x < W - 1 && v <= level;   // lib.rs:224-226
+  const uint32_t pick = floodable ? pick_drlu(d, r, l, u) : 0u;
+  if (x < W && y < H) lout[(size_t)y * W + x] = c ? c : pick;
+  if (pick && x < W && y < H) *counter = 1u;
+}
+
+// vector form (W % 4 == 0, image rows dword aligned): a thread owns 4 consecutive pixels; labels move
+// as 16-byte vectors, the image as one dword; a workgroup covers 1024 pixels of one row
+__global__ __launch_bounds__(256) void k_flood_step4(const uint8_t *__restrict__ img, size_t img_stride,
+                                                     const uint32_t *__restrict__ lin, uint32_t *__restrict__ lout,
+                                                     int H, int W, uint32_t level, uint32_t *counter) {
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= W) return;
+  const int ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  const u32x4_r c = *reinterpret_cast<const u32x4_r *>(lin + (size_t)y * W + x0);
+  const u32x4_r dn = *reinterpret_cast<const u32x4_r *>(lin + (size_t)yp * W + x0);
+  const u32x4_r up = *reinterpret_cast<const u32x4_r *>(lin + (size_t)ym * W + x0);
+  const uint32_t lft = lin[(size_t)y * W + max(x0 - 1, 0)], rgt = lin[(size_t)y * W + min(x0 + 4, W - 1)];
+  const uint32_t iv = *reinterpret_cast<const uint32_t *>(img + (size_t)y * img_stride + x0);
+  const bool row_int = y >= 1 && y < H - 1;
+  const uint32_t cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {dn.x, dn.y, dn.z, dn.w}, uu[4] = {up.x, up.y, up.z, up.w};
+  const uint32_t ll[4] = {lft, c.x, c.y, c.z}, rr[4] = {c.y, c.z, c.w, rgt};
+  uint32_t out[4], any = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + k;
+    const bool floodable = cc[k] == 0u && row_int && x >= 1 && x < W - 1 && ((iv >> (8 * k)) & 0xFFu) <= level;
+    const uint32_t pick = floodable ? pick_drlu(dd[k], rr[k], ll[k], uu[k]) : 0u;
+    out[k] = cc[k] ? cc[k] : pick;
+    any |= pick;
   }
-  if (__syncthreads_or(coloured) && threadIdx.x == 0) atomicAdd(counter, 1u);
+  *reinterpret_cast<u32x4_r *>(lout + (size_t)y * W + x0) = u32x4_r{out[0], out[1], out[2], out[3]};
+  if (any) *counter = 1u;
 }
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter) {
-  dim3 grid((w + 63) / 64, (h + 3) / 4);
-  k_flood_step<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
+  if (h == 0 || w == 0) return hipSuccess;
+  if ((w & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0) {
+    dim3 grid((w / 4 + 255) / 256, h);
+    k_flood_step4<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
+  } else {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    k_flood_step<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
+  }
   return hipGetLastError();
 }
 
