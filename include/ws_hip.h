@@ -206,6 +206,18 @@ int ws_last_arrival_device(ws_ctx *ctx, const uint32_t **d_keys, size_t *h, size
 /* Copies those stamps into the caller's device buffer of n_elems >= h*w words (stream ordered). */
 int ws_copy_last_arrival_device(ws_ctx *ctx, uint32_t *d_dst, size_t n_elems);
 
+/* ---- input preparation (first "next" row) ---------------------------------------
+ *
+ * WatershedUtils::pre_processor / pre_processor_with_max::<MAX> (lib.rs:1081-1173): any numeric
+ * array (any dimension, passed flattened) -> u8 in [0, MAX].  Quirks reproduced as coded: min and
+ * max folds are seeded with 0; values that are not `is_normal` in f64 -- NaN, -inf, subnormals AND
+ * exact 0 -- become NEVER_FILL (255); +inf becomes ALWAYS_FILL (0); the rest is
+ * trunc((x - min) / (max - min) * MAX) in f64.  max_value must be in 1..=254 (the reference asserts). */
+typedef enum ws_dtype { WS_F32 = 0, WS_F64 = 1, WS_I32 = 2, WS_U16 = 3, WS_I16 = 4, WS_U8 = 5 } ws_dtype;
+int ws_pre_processor(ws_ctx *ctx, const void *data, int dtype, size_t n_elems, uint8_t max_value, uint8_t *out);
+int ws_pre_processor_device(ws_ctx *ctx, const void *d_data, int dtype, size_t n_elems, uint8_t max_value,
+                            uint8_t *d_out);
+
 /* ---- one field tiled over several GPUs: row blocks with halo rows ----------------------
  *
  * A rank holds its rows of the global field plus one extra (halo) row on every side that has a

@@ -116,8 +116,29 @@ inline std::vector<std::uint64_t> pack(const std::vector<Seed> &seeds) {
 }
 }  // namespace detail
 
-class WatershedUtils {                     // lib.rs:1069-1198 (find_local_minima; pre_processor is outside this path)
+template <class E> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = WS_F32; };
+template <> struct dtype_of<double> { static constexpr int value = WS_F64; };
+template <> struct dtype_of<std::int32_t> { static constexpr int value = WS_I32; };
+template <> struct dtype_of<std::uint16_t> { static constexpr int value = WS_U16; };
+template <> struct dtype_of<std::int16_t> { static constexpr int value = WS_I16; };
+template <> struct dtype_of<std::uint8_t> { static constexpr int value = WS_U8; };
+
+class WatershedUtils {                     // lib.rs:1069-1198
  public:
+  // lib.rs:1134-1173: pre_processor_with_max::<MAX, T, D>; any dimension, passed as a flat span
+  template <std::uint8_t MAX, class E>
+  std::vector<std::uint8_t> pre_processor_with_max(const E *data, std::size_t n) const {
+    static_assert(MAX < NEVER_FILL && MAX > ALWAYS_FILL, "lib.rs:1143-1144");
+    std::vector<std::uint8_t> out(n);
+    ctx_->check(ws_pre_processor(ctx_->get(), data, dtype_of<E>::value, n, MAX, out.data()));
+    return out;
+  }
+  template <class E>
+  std::vector<std::uint8_t> pre_processor(const E *data, std::size_t n) const {   // lib.rs:1081-1087
+    return pre_processor_with_max<NORMAL_MAX, E>(data, n);
+  }
+
   std::vector<Seed> find_local_minima(ArrayView2<std::uint8_t> img) const {
     const std::size_t cap = ((img.rows ? img.rows - 1 : 0) / 2 + 1) * ((img.cols ? img.cols - 1 : 0) / 2 + 1);
     std::vector<std::uint64_t> rc(2 * cap);

@@ -629,3 +629,42 @@ int ws_or_merge_arrival(const uint8_t *img, size_t h, size_t w, const uint64_t *
   free(seedcol); free(key); free(parent); free(minseed); free(pl.pimg);
   return rc;
 }
+
+/* ---------------------------------------------- pre_processor (lib.rs:1081-1173) -- */
+
+#include <math.h>
+
+static double pre_get(const void *data, int dtype, size_t i) {
+  switch (dtype) {
+    case 0: return (double)((const float *)data)[i];
+    case 1: return ((const double *)data)[i];
+    case 2: return (double)((const int32_t *)data)[i];
+    case 3: return (double)((const uint16_t *)data)[i];
+    case 4: return (double)((const int16_t *)data)[i];
+    default: return (double)((const uint8_t *)data)[i];
+  }
+}
+
+/* dtype: 0 f32, 1 f64, 2 i32, 3 u16, 4 i16, 5 u8.  Returns 0, or -1 when max_value is not in
+ * 1..=254 (the reference asserts, lib.rs:1143-1144). */
+int ws_or_pre_processor(const void *data, int dtype, size_t n, uint8_t max_value, uint8_t *out) {
+  if (max_value >= WS_OR_NEVER_FILL || max_value <= WS_OR_ALWAYS_FILL) return -1;
+  double mn = 0.0, mx = 0.0;                               /* lib.rs:1149, 1154: folds seeded with zero */
+  for (size_t i = 0; i < n; ++i) {
+    const double v = pre_get(data, dtype, i);
+    if (v < mn && isfinite(v)) mn = v;                     /* lib.rs:1149 */
+    if (v > mx && isfinite(v)) mx = v;                     /* lib.rs:1154 */
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const double v = pre_get(data, dtype, i);
+    if (isnormal(v)) {                                     /* lib.rs:1161 */
+      const double normal = (v - mn) / (mx - mn);          /* lib.rs:1163 */
+      out[i] = (uint8_t)(normal * (double)max_value);      /* lib.rs:1164: to_u8 truncates */
+    } else if (isinf(v) && !signbit(v)) {
+      out[i] = WS_OR_ALWAYS_FILL;                          /* lib.rs:1165-1167: +inf */
+    } else {
+      out[i] = WS_OR_NEVER_FILL;                           /* lib.rs:1168-1170: NaN, -inf, subnormal, zero */
+    }
+  }
+  return 0;
+}

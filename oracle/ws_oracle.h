@@ -123,6 +123,10 @@ int ws_or_check_reachable(const uint8_t *img, size_t h, size_t w, const uint64_t
 size_t ws_or_canonicalise(uint64_t *labels, size_t h, size_t w, const uint64_t *seeds_rc,
                           size_t n_seeds);
 
+/* lib.rs:1081-1173: pre_processor / pre_processor_with_max.  dtype: 0 f32, 1 f64, 2 i32, 3 u16, 4 i16,
+ * 5 u8.  Returns 0, or -1 when max_value is outside 1..=254 (the reference asserts). */
+int ws_or_pre_processor(const void *data, int dtype, size_t n, uint8_t max_value, uint8_t *out);
+
 /* ---- second, independent restatement: the arrival-time form ------------------
  * T(p) = max((img[p],1), succ(min_q T(q))) over the 4 neighbours, seeds = -inf,
  * label(p) = label(first q in D,R,L,U with T(q) < T(p)).  Computed with a Dijkstra

@@ -30,6 +30,7 @@ WS_ERR_TOO_LARGE = -10
 WS_ERR_UNSUPPORTED = -11
 
 WS_ENGINE_AUTO, WS_ENGINE_FUSED, WS_ENGINE_SWEEP = 0, 1, 2
+WS_DTYPES = {"float32": 0, "float64": 1, "int32": 2, "uint16": 3, "int16": 4, "uint8": 5}
 
 
 class Options(ctypes.Structure):
@@ -81,6 +82,8 @@ SIGNATURES = {
     "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_last_arrival_device": (ctypes.c_int, [vp, ctypes.POINTER(vp), szp, szp]),
     "ws_copy_last_arrival_device": (ctypes.c_int, [vp, vp, sz]),
+    "ws_pre_processor": (ctypes.c_int, [vp, vp, ctypes.c_int, sz, ctypes.c_uint8, vp]),
+    "ws_pre_processor_device": (ctypes.c_int, [vp, vp, ctypes.c_int, sz, ctypes.c_uint8, vp]),
     "ws_block_init": (ctypes.c_int, [vp, sz, sz, vp, vp, sz, vp, vp]),
     "ws_block_relax": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint8, vp, ctypes.POINTER(ctypes.c_int)]),
     "ws_block_resolve": (ctypes.c_int, [vp, vp, vp, sz, sz, ctypes.POINTER(ctypes.c_int)]),

@@ -201,7 +201,28 @@ class TransformBuilder:
 
 
 class WatershedUtils:
-    """lib.rs:1069-1198 (find_local_minima only: the pre-processor is outside this path)"""
+    """lib.rs:1069-1198"""
+
+    def pre_processor(self, img):
+        """lib.rs:1081-1087: any numeric array -> u8 in [0, NORMAL_MAX]; NaN / -inf / subnormals / exact 0 ->
+        NEVER_FILL, +inf -> ALWAYS_FILL (as the code does, whatever its comments say)."""
+        return self.pre_processor_with_max(img, NORMAL_MAX)
+
+    def pre_processor_with_max(self, img, max_value):
+        """lib.rs:1134-1173 (`pre_processor_with_max::<MAX, _, _>`); any dimension."""
+        a = np.ascontiguousarray(img)
+        if a.dtype.name not in _ffi.WS_DTYPES:
+            raise TypeError(f"unsupported dtype {a.dtype} (supported: {sorted(_ffi.WS_DTYPES)})")
+        if not 0 <= int(max_value) <= 255:
+            raise OverflowError("MAX must fit a u8")
+        if int(max_value) >= NEVER_FILL or int(max_value) <= ALWAYS_FILL:
+            raise AssertionError("MAX must be in 1..=254 (lib.rs:1143-1144)")      # the reference asserts
+        ctx = self._ctx()
+        out = np.empty(a.shape, dtype=np.uint8)
+        rc = _ffi.lib().ws_pre_processor(ctx.handle, a.ctypes.data, _ffi.WS_DTYPES[a.dtype.name], a.size, int(max_value),
+                                         out.ctypes.data)
+        ctx.check(rc)
+        return out
 
     def find_local_minima(self, img):
         """Strict 8-neighbour local MAXIMA of the interior, row-major (lib.rs:1178-1197).

@@ -7,6 +7,7 @@
 #include "../../include/ws_hip.h"
 #include "ws_common.hpp"
 #include "ws_merge.hpp"
+#include "ws_preproc.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -651,6 +652,35 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out) {
   if (h < 2 || w < 2) return WS_OK;
   for (size_t r = 1; r + 1 < h; ++r)
     for (size_t col = 1; col + 1 < w; ++col) out[r * w + col] = 123;   // lib.rs:1532
+  return WS_OK;
+}
+
+// ---- pre-processor (lib.rs:1081-1173) --------------------------------------------------------------
+
+int ws_pre_processor_device(ws_ctx *c, const void *d_data, int dtype, size_t n, uint8_t max_value, uint8_t *d_out) {
+  if (!c || (n && (!d_data || !d_out))) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (preproc_elem_size(dtype) == 0) return fail(c, WS_ERR_BAD_ARG, "unknown dtype");
+  if (max_value >= WS_NEVER_FILL) return fail(c, WS_ERR_MAX_TOO_HIGH, "MAX must be < NEVER_FILL (lib.rs:1143)");
+  if (max_value <= WS_ALWAYS_FILL) return fail(c, WS_ERR_MAX_TOO_LOW, "MAX must be > ALWAYS_FILL (lib.rs:1144)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->counts, 2 * PREPROC_BLOCKS * sizeof(double)))) return rc;
+  HIP_TRY(c, preprocess(c->stream, d_data, dtype, n, max_value, (double *)c->counts.p, d_out));
+  return WS_OK;
+}
+
+int ws_pre_processor(ws_ctx *c, const void *data, int dtype, size_t n, uint8_t max_value, uint8_t *out) {
+  if (!c || (n && (!data || !out))) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  const size_t es = preproc_elem_size(dtype);
+  if (es == 0) return fail(c, WS_ERR_BAD_ARG, "unknown dtype");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->aux, (n ? n : 1) * es))) return rc;
+  if ((rc = ensure(c, c->img, n ? n : 1))) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->aux.p, data, n * es, hipMemcpyHostToDevice, c->stream));
+  if ((rc = ws_pre_processor_device(c, c->aux.p, dtype, n, max_value, (uint8_t *)c->img.p))) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(out, c->img.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return WS_OK;
 }
 

@@ -78,6 +78,8 @@ def lib():
         L.ws_or_merge_arrival.restype = ctypes.c_int
         L.ws_or_merge_arrival.argtypes = [_u8p, _sz, _sz, _u64p, _sz, ctypes.c_uint8, ctypes.c_int, _u64p,
                                           ctypes.c_void_p, ctypes.c_void_p]
+        L.ws_or_pre_processor.restype = ctypes.c_int
+        L.ws_or_pre_processor.argtypes = [ctypes.c_void_p, ctypes.c_int, _sz, ctypes.c_uint8, _u8p]
         L.ws_or_max_threads.restype = ctypes.c_int
         L.ws_or_segment_par.restype = ctypes.c_int
         L.ws_or_segment_par.argtypes = [_u8p, _sz, _sz, _u64p, _sz, ctypes.c_uint8, ctypes.c_int, _u64p,
@@ -309,3 +311,30 @@ def canonicalise(labels, seeds):
     h, w = lab.shape
     n = lib().ws_or_canonicalise(_p(lab, _u64p), h, w, _p(s, _u64p), ns)
     return lab, int(n)
+
+
+DTYPES = {"float32": 0, "float64": 1, "int32": 2, "uint16": 3, "int16": 4, "uint8": 5}
+
+
+def pre_processor(arr, max_value=254):
+    a = np.ascontiguousarray(arr)
+    out = np.empty(a.shape, dtype=np.uint8)
+    rc = lib().ws_or_pre_processor(a.ctypes.data, DTYPES[a.dtype.name], a.size, max_value, _p(out, _u8p))
+    if rc != 0:
+        raise AssertionError("MAX must be in 1..=254 (lib.rs:1143-1144)")
+    return out
+
+
+def pre_processor_numpy(arr, max_value=254):
+    """Independent numpy restatement of lib.rs:1134-1173 (IEEE f64 arithmetic, same operation order)."""
+    x = np.asarray(arr).astype(np.float64)
+    fin = np.isfinite(x)
+    mn = min(0.0, float(x[fin].min())) if fin.any() else 0.0
+    mx = max(0.0, float(x[fin].max())) if fin.any() else 0.0
+    out = np.full(x.shape, 255, dtype=np.uint8)
+    normal = fin & (np.abs(x) >= np.finfo(np.float64).tiny)
+    with np.errstate(all="ignore"):
+        q = ((x - mn) / (mx - mn)) * float(max_value)
+    out[normal] = np.trunc(q[normal]).astype(np.uint8)
+    out[np.isposinf(x)] = 0
+    return out
