@@ -53,18 +53,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    comm_dev = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        # The data path has no collective (independent slices); RCCL only carries the barrier and the
+        # max-over-ranks of the timed region.  One rank per GPU is the contract; when ranks outnumber
+        # the visible GPUs (a rehearsal on a one-GPU box) RCCL refuses duplicate devices, so the same two
+        # tiny collectives run over gloo instead.
+        backend = os.environ.get("WS_BENCH_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
+        dist.init_process_group(backend)
+        comm_dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    ge.build_hip()
+    if rank == 0:
+        ge.build_hip()             # a no-op when the in-tree .so is current
+    if world > 1:
+        dist.barrier()
     pkg = ge.load_package()
     import importlib
     dev = importlib.import_module("rustronomy_watershed_amd.device")
-    torch.cuda.set_device(local_rank)
-    eng = dev.DeviceEngine(local_rank, engine=pkg.ENGINE_SWEEP if args.engine == "sweep" else pkg.ENGINE_FUSED)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)      # one rank per GPU on a real node
+    torch.cuda.set_device(dev_index)
+    eng = dev.DeviceEngine(dev_index, engine=pkg.ENGINE_SWEEP if args.engine == "sweep" else pkg.ENGINE_FUSED)
 
     H = W = args.size
     npx = H * W
@@ -102,7 +114,7 @@ def main():
     barrier()
     eng.ctx.set_profiling(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+    t = torch.tensor([dt], dtype=torch.float64, device=comm_dev if world > 1 else eng.device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
