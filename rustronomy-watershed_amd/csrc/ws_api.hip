@@ -71,8 +71,9 @@ constexpr int FLAG_REFS = FLAG_STATS + 2 * FLAG_SLOT;        // [FLAG_SLOT] stri
 constexpr int FLAG_MISC = FLAG_REFS + FLAG_SLOT;
 constexpr int FLAG_OVERFLOW = FLAG_MISC + 0;
 constexpr int FLAG_SEED_ERR = FLAG_MISC + 1;
-constexpr int FLAG_TOTAL = FLAG_MISC + 2;                    // minima total
-constexpr int FLAG_SWEEP = FLAG_MISC + 3;                    // sweep engine: tiles coloured in the last step
+constexpr int FLAG_UNSORTED = FLAG_MISC + 2;                 // seed list not strictly increasing (must follow FLAG_SEED_ERR)
+constexpr int FLAG_TOTAL = FLAG_MISC + 3;                    // minima total
+constexpr int FLAG_SWEEP = FLAG_MISC + 4;                    // sweep engine: tiles coloured in the last step
 constexpr int FLAG_WORDS = FLAG_MISC + 16;
 
 PassFlags make_pf(ws_ctx *c) {
@@ -226,7 +227,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   {
     Span sp(c, KC_OTHER);
     HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
     if (c->profiling) HIP_TRY(c, hipMemsetAsync(flags + FLAG_STATS, 0, 2 * FLAG_SLOT * sizeof(uint32_t), c->stream));
     // stamps are not touched here: relaxation pass 0 derives them from the painted label plane
     HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, nullptr, flags + FLAG_SEED_ERR));
@@ -289,7 +290,7 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   uint32_t *cur = d_labels, *nxt = (uint32_t *)c->labels2.p;
   c->have_keys = false;
   HIP_TRY(c, hipMemsetAsync(cur, 0, n * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
@@ -700,7 +701,7 @@ int ws_block_init(ws_ctx *c, size_t h, size_t w, const uint32_t *d_seeds_rc, con
   const size_t n = h * w;
   HIP_TRY(c, fill_u32(c->stream, d_keys, n, KEY_INF));
   if (n) HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds_rc, d_colours, n_seeds, (int)h, (int)w, d_labels, d_keys, flags + FLAG_SEED_ERR));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

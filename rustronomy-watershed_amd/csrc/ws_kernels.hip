@@ -71,7 +71,7 @@ hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w
 // them lands), then a fix-up pass in which a seed whose colour is larger than what it finds there
 // raises the pixel with atomicMax -- only duplicate seeds ever issue an atomic.
 __global__ void k_scatter_seeds(const uint32_t *__restrict__ seeds_rc, const uint32_t *__restrict__ colours, size_t n, int ph,
-                                int pw, uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
+                                int pw, uint32_t *labels, uint32_t *keys, uint32_t *err_flag, uint32_t *unsorted_flag) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
@@ -80,11 +80,18 @@ __global__ void k_scatter_seeds(const uint32_t *__restrict__ seeds_rc, const uin
     const size_t p = (size_t)rc.x * pw + rc.y;
     labels[p] = colours ? colours[i] : (uint32_t)(i + 1);
     if (keys) keys[p] = 0u;
+    // a strictly increasing (row-major) list -- what find_local_minima returns -- cannot hold duplicates;
+    // anything else arms the fix-up pass (plain idempotent store)
+    if (i + 1 < n) {
+      const uint2 nx = reinterpret_cast<const uint2 *>(seeds_rc)[i + 1];
+      if ((size_t)nx.x * pw + nx.y <= p) *unsorted_flag = 1u;
+    }
   }
 }
 
 __global__ void k_scatter_fixup(const uint32_t *__restrict__ seeds_rc, const uint32_t *__restrict__ colours, size_t n, int ph,
-                                int pw, uint32_t *labels) {
+                                int pw, uint32_t *labels, const uint32_t *unsorted_flag) {
+  if (*unsorted_flag == 0u) return;          // no duplicates possible: nothing to fix
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
@@ -96,14 +103,15 @@ __global__ void k_scatter_fixup(const uint32_t *__restrict__ seeds_rc, const uin
   }
 }
 
+// err_flag points at two consecutive words: [0] seed out of bounds, [1] seed list not strictly increasing
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-  k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, keys, err_flag);
+  k_scatter_seeds<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, keys, err_flag, err_flag + 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  k_scatter_fixup<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels);
+  k_scatter_fixup<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, err_flag + 1);
   return hipGetLastError();
 }
 

@@ -55,11 +55,42 @@ __device__ __forceinline__ uint32_t lane_right(uint32_t old, uint32_t v) {    //
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
   return max(min(a, b), min(max(a, b), c));
 }
-__device__ __forceinline__ bool relax_px(uint32_t &t, uint32_t b, uint32_t u, uint32_t d, uint32_t l, uint32_t r) {
+template <bool TRACK>
+__device__ __forceinline__ void relax_px(uint32_t &t, uint32_t b, uint32_t u, uint32_t d, uint32_t l, uint32_t r, bool &changed) {
   const uint32_t n = med3u(b, min(min(u, d), min(l, r)) + 1u, t);
-  const bool lower = n != t;     // v_cmp + a scalar OR: the flag lives in an SGPR pair
+  if (TRACK) changed |= n != t;      // v_cmp + a scalar OR: the flag lives in an SGPR pair
   t = n;
-  return lower;
+}
+
+typedef uint32_t patch_t[RX_P][RX_P];
+
+// A sweep updates a whole patch row (or column) at a time: its 4 pixels are independent (they use
+// the row's old left/right values), rows (columns) follow each other Gauss-Seidel fashion.
+template <bool TRACK, bool DOWN>
+__device__ __forceinline__ void sweep_rows(patch_t &T, const patch_t &B, const uint32_t (&up)[RX_P], const uint32_t (&dn)[RX_P],
+                                           const uint32_t (&L)[RX_P], const uint32_t (&R)[RX_P], bool &changed) {
+#pragma unroll
+  for (int k = 0; k < RX_P; ++k) {
+    const int r = DOWN ? k : RX_P - 1 - k;
+    const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
+    const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
+#pragma unroll
+    for (int c = 0; c < RX_P; ++c)
+      relax_px<TRACK>(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c], changed);
+  }
+}
+template <bool TRACK, bool RIGHT>
+__device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const uint32_t (&up)[RX_P], const uint32_t (&dn)[RX_P],
+                                           const uint32_t (&L)[RX_P], const uint32_t (&R)[RX_P], bool &changed) {
+#pragma unroll
+  for (int k = 0; k < RX_P; ++k) {
+    const int c = RIGHT ? k : RX_P - 1 - k;
+    const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
+    const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r)
+      relax_px<TRACK>(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1], changed);
+  }
 }
 
 template <int NW>
@@ -79,6 +110,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   // cleared by thread 0 for iteration k + 2 -- one barrier per iteration instead of the three a
   // __syncthreads_or costs
   __shared__ uint32_t s_flag[3];
+  __shared__ uint64_t s_sum[64 * NW];        // per-lane patch checksum taken at load time (parked: VGPRs are at the cap)
 
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const size_t ntiles = (size_t)tilesX * tilesY;
@@ -205,72 +237,69 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   WS_STAMP(1);
 
   // ---- relaxation ---------------------------------------------------------------------------
-  bool any_lower = from_labels;      // a pass that creates the stamp plane writes every patch
+  // One round = three free-running sweeps (down, right, up), a barrier that publishes the band
+  // boundary rows, then ONE checked sweep (left) on fresh neighbours.  The fixpoint is reached
+  // exactly when that checked sweep changes nothing in the whole tile: every pixel has then been
+  // evaluated against final neighbour values.  Only the checked sweep pays for change tracking, and
+  // a tile that was already converged leaves after 4 sweeps instead of 8.
+  {
+    uint64_t sum_before = 0;         // stamps only ever decrease: a 64-bit patch sum tells "changed" exactly
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r)
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) sum_before += T[r][c];
+    s_sum[tid] = sum_before;
+  }
   uint32_t iters = 0;
   for (; max_iters != 0;) {
     ++iters;
-    bool changed = false;
-    const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
-    const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
-    const uint32_t up[RX_P] = {up4.x, up4.y, up4.z, up4.w};
-    const uint32_t dn[RX_P] = {dn4.x, dn4.y, dn4.z, dn4.w};
-    uint32_t L[RX_P], R[RX_P];
-
-    // sweep down: rows top to bottom, the 4 pixels of a row are independent
+    bool changed = false, untracked = false;
+    uint32_t up[RX_P], dn[RX_P], L[RX_P], R[RX_P];
+    {
+      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
+      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
+      up[0] = up4.x; up[1] = up4.y; up[2] = up4.z; up[3] = up4.w;
+      dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
+    }
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-#pragma unroll
-    for (int r = 0; r < RX_P; ++r) {
-      const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
-      const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
-#pragma unroll
-      for (int c = 0; c < RX_P; ++c)
-        changed |= relax_px(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c]);
-    }
-    // sweep right: columns left to right
+    sweep_rows<false, true>(T, B, up, dn, L, R, untracked);       // down
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-#pragma unroll
-    for (int c = 0; c < RX_P; ++c) {
-      const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
-      const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
-#pragma unroll
-      for (int r = 0; r < RX_P; ++r)
-        changed |= relax_px(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1]);
-    }
-    // sweep up: rows bottom to top
+    sweep_cols<false, true>(T, B, up, dn, L, R, untracked);       // right
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-#pragma unroll
-    for (int r = RX_P - 1; r >= 0; --r) {
-      const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
-      const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
-#pragma unroll
-      for (int c = 0; c < RX_P; ++c)
-        changed |= relax_px(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c]);
-    }
-    // sweep left: columns right to left
-#pragma unroll
-    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-#pragma unroll
-    for (int c = RX_P - 1; c >= 0; --c) {
-      const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
-      const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
-#pragma unroll
-      for (int r = 0; r < RX_P; ++r)
-        changed |= relax_px(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1]);
-    }
-    any_lower |= changed;
-    // publish this band's boundary rows for the bands above / below
+    sweep_rows<false, false>(T, B, up, dn, L, R, untracked);      // up
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
     *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+    __syncthreads();
+    {
+      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
+      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
+      up[0] = up4.x; up[1] = up4.y; up[2] = up4.z; up[3] = up4.w;
+      dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
+    sweep_cols<true, false>(T, B, up, dn, L, R, changed);         // left, checked
     const uint32_t slot = (iters - 1) % 3;
-    if (__builtin_amdgcn_ballot_w64(changed) != 0 && lane == 0) s_flag[slot] = 1;
+    if (__builtin_amdgcn_ballot_w64(changed) != 0) {
+      // a neighbour band reads these rows only if another round follows, i.e. only if someone changed
+      *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+      *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+      if (lane == 0) s_flag[slot] = 1;
+    }
     __syncthreads();
     const bool again = s_flag[slot] != 0;
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
     if (!again || iters >= max_iters) break;
   }
+  uint64_t sum_after = 0;
+#pragma unroll
+  for (int r = 0; r < RX_P; ++r)
+#pragma unroll
+    for (int c = 0; c < RX_P; ++c) sum_after += T[r][c];
+  const bool any_lower = from_labels || sum_after != s_sum[tid];   // a pass that creates the stamp plane writes every patch
   WS_STAMP(2);
 #ifdef WS_DIAG_STAMPS
   if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = iters;
