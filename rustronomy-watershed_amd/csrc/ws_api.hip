@@ -71,7 +71,8 @@ constexpr int FLAG_REFS = FLAG_STATS + 2 * FLAG_SLOT;        // [FLAG_SLOT] stri
 constexpr int FLAG_MISC = FLAG_REFS + FLAG_SLOT;
 constexpr int FLAG_OVERFLOW = FLAG_MISC + 0;
 constexpr int FLAG_SEED_ERR = FLAG_MISC + 1;
-constexpr int FLAG_UNSORTED = FLAG_MISC + 2;                 // seed list not strictly increasing (must follow FLAG_SEED_ERR)
+constexpr int FLAG_UNSORTED = FLAG_MISC + 2;                 // seed list not strictly increasing
+static_assert(FLAG_UNSORTED == FLAG_SEED_ERR + 1, "scatter_seeds writes both words through one pointer");
 constexpr int FLAG_TOTAL = FLAG_MISC + 3;                    // minima total
 constexpr int FLAG_SWEEP = FLAG_MISC + 4;                    // sweep engine: tiles coloured in the last step
 constexpr int FLAG_WORDS = FLAG_MISC + 16;
@@ -246,7 +247,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
     if ((rc = ensure(c, c->refs, NSTRIPE * resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p));
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters));
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {

@@ -64,7 +64,7 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 // ref_count: FLAG_SLOT words of striped counters; ref_list: NSTRIPE * resolve_ref_capacity(h, w) words
 size_t resolve_ref_capacity(int h, int w);
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list);
+                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds = 0xFFFFFFFFu);
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

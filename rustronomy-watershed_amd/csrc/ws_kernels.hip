@@ -334,7 +334,7 @@ typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
-                                                            uint32_t *ref_list, size_t ref_cap) {
+                                                            uint32_t *ref_list, size_t ref_cap, uint32_t max_rounds) {
   // One 66 x 66 LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[LP * LP];
   __shared__ uint32_t s_flag[3];
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     __syncthreads();
     const bool again = s_flag[slot] != 0;
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
-    if (!again) break;
+    if (!again || it + 1 >= max_rounds) break;     // max_rounds: timing experiments only (WS_DEBUG_MAXIT)
   }
   // every pointer is final and in registers: the tile now becomes the painted colours, so that the
   // colour of an in-tile root (a seed) is one LDS read
@@ -495,14 +495,14 @@ size_t resolve_ref_capacity(int h, int w) {
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list) {
+                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t cap = resolve_ref_capacity(h, w);
   hipError_t e = hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
-  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap);
+  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   k_resolve_chase<<<dim3(32, NSTRIPE), 256, 0, s>>>(labels, ref_count, ref_list, cap, n);
