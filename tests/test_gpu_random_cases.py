@@ -1,0 +1,45 @@
+"""Randomised sweep over small shapes, seed placements and options: the HIP engine (both engines,
+host ABI) against the sweep oracle, bit-exact.  One process, ~300 transforms."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_small_cases_bit_exact():
+    ge.build_hip()
+    pkg = ge.load_package()
+    rng = np.random.default_rng(2024)
+    for case in range(150):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 300))
+        kind = case % 5
+        if kind == 0:
+            img = rng.integers(0, 254, (h, w), dtype=np.uint8)
+        elif kind == 1:                                   # few levels: big plateaus, long rings
+            img = rng.integers(0, 4, (h, w), dtype=np.uint8) * 60
+        elif kind == 2:                                   # walls and floors (NEVER_FILL / ALWAYS_FILL)
+            img = rng.choice(np.array([0, 255, 17, 200], dtype=np.uint8), (h, w), p=[0.3, 0.2, 0.3, 0.2])
+        elif kind == 3:                                   # smooth ramp + noise
+            img = ((np.add.outer(np.arange(h), np.arange(w)) * 3 + rng.integers(0, 9, (h, w))) % 254).astype(np.uint8)
+        else:
+            img = np.full((h, w), int(rng.integers(0, 256)), dtype=np.uint8)
+        n_seeds = int(rng.integers(0, max(2, h * w // 12)))
+        seeds = np.stack([rng.integers(0, h, n_seeds), rng.integers(0, w, n_seeds)], axis=1).astype(np.uint64)   # duplicates, borders allowed
+        max_level = int(rng.choice([1, 3, 17, 128, 254]))
+        edge = bool(rng.integers(0, 2))
+        want = ol.segment(img, seeds, max_level=max_level, edge=edge)
+        for engine in ((pkg.ENGINE_FUSED, pkg.ENGINE_SWEEP) if case % 3 == 0 else (pkg.ENGINE_FUSED,)):
+            b = pkg.TransformBuilder.new().set_max_water_lvl(max_level).set_engine(engine)
+            if edge:
+                b.enable_edge_correction()
+            got = b.build_segmenting().transform(img, seeds)
+            assert got.shape == want.shape and (got == want).all(), (case, h, w, kind, n_seeds, max_level, edge, engine)
+        if case % 10 == 0 and h * w > 0:                  # merging: final canonical partition
+            mer = pkg.TransformBuilder.new().set_max_water_lvl(max_level)
+            if edge:
+                mer.enable_edge_correction()
+            got = mer.build_merging().transform_final(img, seeds)
+            assert (got == ol.merge_arrival(img, seeds, max_level=max_level, edge=edge)).all(), (case, "merge")
