@@ -10,8 +10,12 @@
 
 namespace wsk {
 
+// Reads of the forest may be stale: parents only ever decrease along a chain, so an old value is
+// still an ancestor and the CAS that hooks a root returns the true state.  That makes an ordinary
+// L1-cached load legal here (workgroup scope = a plain global_load the compiler will not hoist);
+// the agent-scope form bypasses L1 and made every find() of the one surviving root an L2 round trip.
 __device__ __forceinline__ uint32_t ld_parent(const uint32_t *parent, uint32_t x) {
-  return __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
@@ -262,23 +266,119 @@ hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *siz
 
 // ---- final-only path ---------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_union_image(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
-                                                     int H, int W, int segs, uint32_t *parent) {
-  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
-  PixelItems it;
-  gather_items(keys, labels, H, W, y, seg * MSEG + threadIdx.x * 4, it);
+// One launch, 64x64 tiles.  Joining every crossing pixel pair in the global forest costs ~60 M
+// unions that all end at the one surviving root; instead each tile first joins its own coloured
+// pixels in an LDS union-find (adjacency rule of find_merge: one endpoint of a pair must be an
+// interior pixel, lib.rs:411-434), takes the smallest colour of every local component, and only then
+// touches the global forest: once per colour REGION of a component (its top-left pixels) and once
+// per crossing pair on the tile's right / bottom edge -- ~6x fewer global unions, most of them local.
+constexpr int UT = 64;                                   // tile side
+constexpr int UT_PX = UT * UT / 256;                     // pixels per thread (16): column strips as in k_resolve_local
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *P, uint32_t x) {
+  for (;;) {
+    const uint32_t p = P[x];
+    if (p == x) return x;
+    const uint32_t g = P[p];
+    if (g == p) return p;
+    atomicMin(&P[x], g);
+    x = g;
+  }
+}
+__device__ __forceinline__ void lds_union(uint32_t *P, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = lds_find(P, a);
+    b = lds_find(P, b);
+    if (a == b) return;
+    if (a > b) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t old = atomicCAS(&P[b], b, a);
+    if (old == b) return;
+    b = old;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_union_tiles(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
+                                                     int H, int W, int tilesX, uint32_t *parent) {
+  __shared__ uint32_t sP[UT * UT];        // local forest over the tile's pixels
+  __shared__ uint32_t sMin[UT * UT];      // smallest colour of a local component, kept at its root
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
+  const int x0 = tile_x * UT, y0 = tile_y * UT;
+  const int gx = x0 + lane, gy0 = y0 + strip * UT_PX;
+  const int gxc = min(gx, W - 1);
+
+  uint32_t col[UT_PX], colR[UT_PX];       // colour of the pixel / of its right neighbour; 0 = uncoloured or outside
+  uint32_t colD_last;                     // colour below the strip's last pixel
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (it.er_lvl[k] != 0xFFFFFFFFu) uf_union(parent, it.er[k].x, it.er[k].y);
-    if (it.ed_lvl[k] != 0xFFFFFFFFu) uf_union(parent, it.ed[k].x, it.ed[k].y);
+  for (int i = 0; i < UT_PX; ++i) {
+    const int gy = gy0 + i, gyc = min(gy, H - 1);
+    const size_t g = (size_t)gyc * W + gxc;
+    const uint32_t k = keys[g], l = labels[g];
+    const uint32_t kr = keys[(size_t)gyc * W + min(gx + 1, W - 1)], lr = labels[(size_t)gyc * W + min(gx + 1, W - 1)];
+    col[i] = (gy < H && gx < W && k != KEY_INF) ? l : 0u;
+    colR[i] = (gy < H && gx + 1 < W && kr != KEY_INF) ? lr : 0u;
+    sP[(strip * UT_PX + i) * UT + lane] = (uint32_t)((strip * UT_PX + i) * UT + lane);
+    sMin[(strip * UT_PX + i) * UT + lane] = 0xFFFFFFFFu;
+  }
+  {
+    const int gy = gy0 + UT_PX, gyc = min(gy, H - 1);
+    const uint32_t k = keys[(size_t)gyc * W + gxc], l = labels[(size_t)gyc * W + gxc];
+    colD_last = (gy < H && gx < W && k != KEY_INF) ? l : 0u;
+  }
+  __syncthreads();
+
+  // local unions: right and down neighbours inside the tile (any colours: touching lakes merge)
+#pragma unroll
+  for (int i = 0; i < UT_PX; ++i) {
+    if (col[i] == 0u) continue;
+    const int ly = strip * UT_PX + i, gy = gy0 + i;
+    const bool ip = interior(gy, gx, H, W);
+    const uint32_t cell = (uint32_t)(ly * UT + lane);
+    if (lane + 1 < UT && colR[i] != 0u && (ip || interior(gy, gx + 1, H, W))) lds_union(sP, cell, cell + 1);
+    const uint32_t cd = i == UT_PX - 1 ? colD_last : col[i + 1];
+    if (ly + 1 < UT && cd != 0u && (ip || interior(gy + 1, gx, H, W))) lds_union(sP, cell, cell + UT);
+  }
+  __syncthreads();
+  uint32_t root[UT_PX];
+#pragma unroll
+  for (int i = 0; i < UT_PX; ++i) {
+    root[i] = col[i] ? lds_find(sP, (uint32_t)((strip * UT_PX + i) * UT + lane)) : 0u;
+    if (col[i]) atomicMin(&sMin[root[i]], col[i]);
+  }
+  __syncthreads();
+
+  // colour of the left neighbour, fetched with every lane active (a shuffle under a divergent
+  // branch would read inactive lanes)
+  uint32_t colL[UT_PX];
+#pragma unroll
+  for (int i = 0; i < UT_PX; ++i) {
+    const uint32_t v = __shfl_up(col[i], 1, 64);
+    colL[i] = lane > 0 ? v : 0u;
+  }
+
+  // global unions
+#pragma unroll
+  for (int i = 0; i < UT_PX; ++i) {
+    if (col[i] == 0u) continue;
+    const int ly = strip * UT_PX + i, gy = gy0 + i;
+    const uint32_t cmin = sMin[root[i]];
+    // (a) one union per colour region of the component: the pixel has no same-coloured pixel of its
+    //     own tile to the left, nor above inside this thread's strip (a region's top-left pixel
+    //     always qualifies; the strip above belongs to another wave and counts as "different")
+    const uint32_t cu = i > 0 ? col[i - 1] : 0u;
+    if (col[i] != cmin && colL[i] != col[i] && cu != col[i]) uf_union(parent, col[i], cmin);
+    // (b) crossing pairs over the tile's right and bottom edge
+    const bool ip = interior(gy, gx, H, W);
+    if (lane == UT - 1 && colR[i] != 0u && colR[i] != col[i] && (ip || interior(gy, gx + 1, H, W))) uf_union(parent, col[i], colR[i]);
+    if (ly == UT - 1 && colD_last != 0u && colD_last != col[i] && (ip || interior(gy + 1, gx, H, W))) uf_union(parent, col[i], colD_last);
   }
 }
 
 hipError_t union_image(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
                        uint32_t *parent) {
   if (h == 0 || w == 0) return hipSuccess;
-  const int segs = (w + MSEG - 1) / MSEG;
-  k_union_image<<<h * segs, 256, 0, s>>>(keys, labels, h, w, segs, parent);
+  const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
+  k_union_tiles<<<tx * ty, 256, 0, s>>>(keys, labels, h, w, tx, parent);
   return hipGetLastError();
 }
 
