@@ -219,7 +219,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   const size_t ntiles = (size_t)tiles_of(pw) * tiles_of(ph);
   int rc;
   if ((rc = ensure(c, c->keys, (n ? n : 1) * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(c, c->stamps, (ntiles ? ntiles : 1) * 4 * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->stamps, std::max(ntiles, relax_tiles(ph, pw)) * 4 * 2 * sizeof(uint32_t)))) return rc;
   uint32_t *keys = (uint32_t *)c->keys.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
   uint32_t *stamps = (uint32_t *)c->stamps.p;
@@ -717,9 +717,8 @@ int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   *changed = 0;
   if (h * w == 0) return WS_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t ntiles = (size_t)tiles_of((int)w) * tiles_of((int)h);
   int rc;
-  if ((rc = ensure(c, c->stamps, ntiles * 4 * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->stamps, relax_tiles((int)h, (int)w) * 4 * 2 * sizeof(uint32_t)))) return rc;
   uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY, 0, FLAG_SLOT * sizeof(uint32_t), c->stream));

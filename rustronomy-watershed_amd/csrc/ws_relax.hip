@@ -14,7 +14,16 @@
 //     for before the next is issued -- that serialised ~50 round trips per thread in the first
 //     version of this engine);
 //   * one iteration = four sweeps (down, right, up, left); a sweep updates a whole patch row (or
-//     column) at a time, i.e. 4 independent pixel updates, so dependency chains are 4 long.
+//     column) at a time, i.e. 4 independent pixel updates, so dependency chains are 4 long;
+//   * TWO tilings alternate: even passes use the grid anchored at (0, 0), odd passes the grid shifted
+//     by half a tile (128, 2*NW), so the borders of one pass lie in the middle of the next pass's
+//     tiles.  On the bench field 99.3 % of the stamps are final after pass 0 and every wrong one lies
+//     within 8 px of a tile border (tools/exp_apron.py): the shifted pass repairs them with correct
+//     surroundings, instead of the 3-4 passes it takes to walk a correction back and forth over the
+//     same border.  A tile runs in pass k iff a tile of pass k-1 changed one of ITS border pixels
+//     inside the quadrant the two tiles share: a pixel equation can only be left violated next to a
+//     border pixel that a neighbour changed after it was read, and that border pixel sits in the
+//     interior (or halo) of exactly the tile of the other grid that owns the pixel.
 //
 // What the measurements said (tools/diag_relax.hip, per-workgroup s_memrealtime stamps, MI355X):
 // with ~5 global atomics per tile on shared words (statistics + convergence counters) a full pass
@@ -23,6 +32,8 @@
 // words are plain stores of 1 into striped slots (idempotent), statistics are striped counters
 // that exist only when profiling is on.
 #include "ws_common.hpp"
+
+#include <cstdlib>
 
 namespace wsk {
 
@@ -93,10 +104,49 @@ __device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const u
   }
 }
 
+// Which tiles of the chunk starting at `first` have to run in this pass?  Lane k answers for tile
+// first + k; the ballot is the to-do list.  tilesX x tilesY is this pass's grid, otherX x otherY the
+// grid of the previous pass.
 template <int NW>
+__device__ __forceinline__ unsigned long long relax_todo(int first, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
+                                                         int otherY, int shifted, uint32_t pass,
+                                                         const uint32_t *__restrict__ stamps_prev) {
+  constexpr int TH = NW * RX_P;
+  const int lane = threadIdx.x & 63;
+  const int ox = shifted ? RX_TW / 2 : 0, oy = shifted ? TH / 2 : 0;
+  const int t = first + lane;
+  const bool mine = lane < chunk && t < tilesX * tilesY;
+  const int tx = mine ? t % tilesX : 0, ty = mine ? t / tilesX : 0;
+  // a shifted grid can have a last row/column outside the plane
+  bool run = mine && tx * RX_TW - ox < W && ty * TH - oy < H;
+  if (pass != 0) {
+    // Quadrant (qx, qy) of a tile is quadrant (1-qx, 1-qy) of one tile of the previous pass's grid:
+    // did that tile change a border pixel there?  Four independent loads on clamped indices.
+    bool flagged = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int qx = q & 1, qy = q >> 1;
+      const int oi = tx + qx - (shifted ? 1 : 0), oj = ty + qy - (shifted ? 1 : 0);
+      const bool ok = oi >= 0 && oi < otherX && oj >= 0 && oj < otherY;
+      const size_t ot = (size_t)(ok ? oj : 0) * otherX + (ok ? oi : 0);
+      const uint32_t st = stamps_prev[ot * 4 + (3 - q)];
+      flagged |= ok && st == pass;
+    }
+    run = run && flagged;
+  }
+  return __builtin_amdgcn_ballot_w64(run);
+}
+
+// CHUNKED = false: one tile per workgroup -- the passes in which (nearly) every tile runs.
+// CHUNKED = true: `chunk` (<= 64) consecutive tiles per workgroup, run one after the other -- the late
+// passes, in which few tiles run: a pass with nothing to do costs 1/chunk of the workgroup launches.
+// (One body for both, not a shared device function: at the 80-VGPR cap the out-of-line form spilled.)
+template <int NW, bool CHUNKED>
 __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
-                                                      int H, int W, int tilesX, int tilesY, uint32_t max_level,
-                                                      uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
+                                                      int H, int W, int tilesX, int tilesY, int otherX, int otherY,
+                                                      int shifted, int chunk, uint32_t max_level, uint32_t pass,
+                                                      const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
+                                                      PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels) {
   constexpr int TH = NW * RX_P;
   // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
@@ -112,30 +162,43 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   __shared__ uint32_t s_flag[3];
   __shared__ uint64_t s_sum[64 * NW];        // per-lane patch checksum taken at load time (parked: VGPRs are at the cap)
 
-  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
-  const size_t ntiles = (size_t)tilesX * tilesY;
-  const uint32_t *stamps_prev = stamps + ((pass + 1) & 1) * ntiles * 4;
-  uint32_t *stamps_cur = stamps + (pass & 1) * ntiles * 4;
+
   // the first wave of workgroup 0 clears the next pass's convergence slot
   if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
     pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
-  if (pass != 0) {
-    // did a neighbour change the edge it shares with this tile in the previous pass?  Four
-    // independent loads on clamped indices, one decision.
-    const int t = tile_y * tilesX + tile_x;
-    const uint32_t su = stamps_prev[(size_t)(tile_y > 0 ? t - tilesX : t) * 4 + 1];
-    const uint32_t sd = stamps_prev[(size_t)(tile_y + 1 < tilesY ? t + tilesX : t) * 4 + 0];
-    const uint32_t sl = stamps_prev[(size_t)(tile_x > 0 ? t - 1 : t) * 4 + 3];
-    const uint32_t sr = stamps_prev[(size_t)(tile_x + 1 < tilesX ? t + 1 : t) * 4 + 2];
-    const bool run = (tile_y > 0 && su == pass) | (tile_y + 1 < tilesY && sd == pass) | (tile_x > 0 && sl == pass) |
-                     (tile_x + 1 < tilesX && sr == pass);
-    if (!run) return;
+  const int first = CHUNKED ? (int)blockIdx.x * chunk : (int)blockIdx.x;
+  unsigned long long todo = 1;
+  if (CHUNKED) {
+    todo = relax_todo<NW>(first, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
+    if (todo == 0) return;
+  } else {
+    const int tx = first % tilesX, ty = first / tilesX;
+    if (tx * RX_TW - (shifted ? RX_TW / 2 : 0) >= W || ty * TH - (shifted ? TH / 2 : 0) >= H) return;
+    if (pass != 0) {       // the same test as relax_todo, on scalars (workgroup uniform)
+      bool run = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int qx = q & 1, qy = q >> 1;
+        const int oi = tx + qx - (shifted ? 1 : 0), oj = ty + qy - (shifted ? 1 : 0);
+        const bool ok = oi >= 0 && oi < otherX && oj >= 0 && oj < otherY;
+        const size_t ot = (size_t)(ok ? oj : 0) * otherX + (ok ? oi : 0);
+        const uint32_t st = stamps_prev[ot * 4 + (3 - q)];
+        run |= ok && st == pass;
+      }
+      if (!run) return;
+    }
   }
+  for (;;) {
+  // re-derived per tile on purpose (the asm hides the value from loop-invariant hoisting): hoisted
+  // per-lane addresses pushed the chunked variant over the 80-VGPR cap and into scratch
+  int tid = threadIdx.x;
+  if (CHUNKED) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, band = tid >> 6;
+  const int tile = CHUNKED ? first + (int)__builtin_ctzll(todo) : first;
+  const int tile_x = tile % tilesX, tile_y = tile / tilesX;
+  const int x0 = tile_x * RX_TW - (shifted ? RX_TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
   WS_STAMP(0);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, band = tid >> 6;
-  const int x0 = tile_x * RX_TW, y0 = tile_y * TH;
   const int gx0 = x0 + lane * RX_P, gyb = y0 + band * RX_P;
   if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
 
@@ -143,10 +206,14 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   uint32_t T[RX_P][RX_P], B[RX_P][RX_P], halo[RX_P];
   // fast path (workgroup uniform): the tile lies inside the image in x and image rows can be read
   // as aligned dwords -> one 16-byte stamp load and one 4-byte image load per lane and row
-  const bool fast = (x0 + RX_TW <= W) && ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
+  // (patches outside the plane read a clamped address and are masked afterwards: with W % 4 == 0 a
+  // patch is either wholly inside or wholly outside)
+  const bool fast = W >= RX_P && ((x0 >= 0 && x0 + RX_TW <= W) || (W & 3) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
+  const int gxc0 = min(max(gx0, 0), max(W - RX_P, 0));
   // tile halo columns: lanes 0..31 fetch the column left of the tile, lanes 32..63 the one right of
   // it; only lane 0 / lane 63 ever use the value (as the DPP `old` operand)
-  const int xh = lane < 32 ? (x0 > 0 ? x0 - 1 : 0) : (x0 + RX_TW < W ? x0 + RX_TW : W - 1);
+  const int xh = min(max(lane < 32 ? x0 - 1 : x0 + RX_TW, 0), W - 1);
   const bool xh_ok = lane < 32 ? x0 > 0 : x0 + RX_TW < W;
   const int gy_halo_raw = band == 0 ? y0 - 1 : y0 + TH;
   const int gy_halo = min(max(gy_halo_raw, 0), H - 1);
@@ -161,12 +228,12 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     uint32_t iv[RX_P];
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
-      const int gyc = min(gyb + r, H - 1);
-      kv[r] = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gyc * W + gx0);
-      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gx0);
+      const int gyc = min(max(gyb + r, 0), H - 1);
+      kv[r] = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gyc * W + gxc0);
+      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
       halo[r] = ksrc[(size_t)gyc * W + xh];
     }
-    halo_row = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gy_halo * W + gx0);
+    halo_row = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gy_halo * W + gxc0);
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       T[r][0] = kv[r].x; T[r][1] = kv[r].y; T[r][2] = kv[r].z; T[r][3] = kv[r].w;
@@ -176,19 +243,19 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   } else {
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
-      const int gyc = min(gyb + r, H - 1);
+      const int gyc = min(max(gyb + r, 0), H - 1);
 #pragma unroll
       for (int c = 0; c < RX_P; ++c) {
-        const int gxc = min(gx0 + c, W - 1);
+        const int gxc = min(max(gx0 + c, 0), W - 1);
         T[r][c] = ksrc[(size_t)gyc * W + gxc];
         B[r][c] = img[(size_t)gyc * img_stride + gxc];
       }
       halo[r] = ksrc[(size_t)gyc * W + xh];
     }
-    halo_row.x = ksrc[(size_t)gy_halo * W + min(gx0 + 0, W - 1)];
-    halo_row.y = ksrc[(size_t)gy_halo * W + min(gx0 + 1, W - 1)];
-    halo_row.z = ksrc[(size_t)gy_halo * W + min(gx0 + 2, W - 1)];
-    halo_row.w = ksrc[(size_t)gy_halo * W + min(gx0 + 3, W - 1)];
+    halo_row.x = ksrc[(size_t)gy_halo * W + min(max(gx0 + 0, 0), W - 1)];
+    halo_row.y = ksrc[(size_t)gy_halo * W + min(max(gx0 + 1, 0), W - 1)];
+    halo_row.z = ksrc[(size_t)gy_halo * W + min(max(gx0 + 2, 0), W - 1)];
+    halo_row.w = ksrc[(size_t)gy_halo * W + min(max(gx0 + 3, 0), W - 1)];
   }
   if (from_labels) {
 #pragma unroll
@@ -203,11 +270,11 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
 #pragma unroll
   for (int r = 0; r < RX_P; ++r) {
     const int gy = gyb + r;
-    const bool row_ok = gy < H, row_int = gy >= 1 && gy < H - 1;
+    const bool row_ok = gy >= 0 && gy < H, row_int = gy >= 1 && gy < H - 1;
 #pragma unroll
     for (int c = 0; c < RX_P; ++c) {
       const int gx = gx0 + c;
-      if (!(row_ok && gx < W)) T[r][c] = KEY_INF;
+      if (!(row_ok && gx >= 0 && gx < W)) T[r][c] = KEY_INF;
       // bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224);
       // everything else, and every seed (stamp 0 < base), is pinned at its current stamp: b = t
       const uint32_t v = B[r][c];
@@ -218,10 +285,10 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   }
   {
     const bool ok = gy_halo_raw >= 0 && gy_halo_raw < H;
-    if (!(ok && gx0 + 0 < W)) halo_row.x = KEY_INF;
-    if (!(ok && gx0 + 1 < W)) halo_row.y = KEY_INF;
-    if (!(ok && gx0 + 2 < W)) halo_row.z = KEY_INF;
-    if (!(ok && gx0 + 3 < W)) halo_row.w = KEY_INF;
+    if (!(ok && gx0 + 0 >= 0 && gx0 + 0 < W)) halo_row.x = KEY_INF;
+    if (!(ok && gx0 + 1 >= 0 && gx0 + 1 < W)) halo_row.y = KEY_INF;
+    if (!(ok && gx0 + 2 >= 0 && gx0 + 2 < W)) halo_row.z = KEY_INF;
+    if (!(ok && gx0 + 3 >= 0 && gx0 + 3 < W)) halo_row.w = KEY_INF;
     if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][lane * RX_P]) = halo_row;
     if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NW + 1][lane * RX_P]) = halo_row;
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
@@ -308,16 +375,16 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   // ---- write back the patches that changed (16 B per lane and row), ring-carry check, edge flags
   uint32_t e = 0, ovf = 0;
   if (any_lower) {
-    const bool full_x = gx0 + RX_P <= W;
+    const bool full_x = gx0 >= 0 && gx0 + RX_P <= W;
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       const int gy = gyb + r;
-      if (gy < H) {
+      if (gy >= 0 && gy < H) {
         if (full_x) {
           *reinterpret_cast<u32x4_t *>(keys + (size_t)gy * W + gx0) = u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]};
         } else {
 #pragma unroll
-          for (int c = 0; c < RX_P; ++c) if (gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
+          for (int c = 0; c < RX_P; ++c) if (gx0 + c >= 0 && gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
         }
       }
 #pragma unroll
@@ -325,18 +392,20 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
         ovf |= (T[r][c] != 0u && T[r][c] < KEY_INF && (T[r][c] & RING_MASK) == 0u);
     }
     e |= 16u;
+    // bit q: a BORDER pixel of the tile inside quadrant q = 2*(lower half) + (right half) changed
+    const uint32_t qbit = 1u << ((band >= NW / 2 ? 2 : 0) + (lane >= 32 ? 1 : 0));
     if (band == 0) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][lane * RX_P]);
-      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= 1u;
+      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit;
     }
     if (band == NW - 1) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][lane * RX_P]);
-      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= 2u;
+      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit;
     }
     if (lane == 0 || lane == 63) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r)
-        if (sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] != T[r][lane == 0 ? 0 : 3]) e |= lane == 0 ? 4u : 8u;
+        if (sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] != T[r][lane == 0 ? 0 : 3]) e |= qbit;
     }
   }
   if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
@@ -361,22 +430,46 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     }
   }
   WS_STAMP(3);
+  // next tile of the chunk: every wave is past its last read of the shared arrays (barrier above)
+  if (!CHUNKED) break;
+  todo &= todo - 1;
+  if (todo == 0) break;
+  }
 }
 
 constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
 
+// capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column
 size_t relax_tiles(int h, int w) {
   const int th = RX_NW * RX_P;
-  return (size_t)((w + RX_TW - 1) / RX_TW) * ((h + th - 1) / th);
+  return (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
 }
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels) {
   const int th = RX_NW * RX_P;
-  const int tx = (w + RX_TW - 1) / RX_TW, ty = (h + th - 1) / th;
-  k_relax<RX_NW><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, max_level, pass, stamps, pf, max_iters,
-                                                pass == 0 ? seed_labels : nullptr);
+  const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + th - 1) / th;     // grid anchored at (0, 0): even passes
+  const int sx = ax + 1, sy = ay + 1;                                 // grid shifted by half a tile: odd passes
+  const int shifted = (int)(pass & 1u);
+  const int tx = shifted ? sx : ax, ty = shifted ? sy : ay;
+  const size_t cap = (size_t)sx * sy * 4;
+  const uint32_t *prev = stamps + ((pass + 1) & 1) * cap;
+  uint32_t *cur = stamps + (pass & 1) * cap;
+  const int ox_ = shifted ? ax : sx, oy_ = shifted ? ay : sy;        // the previous pass's grid
+  // passes 0 and 1 run every tile and pass 2 about half of them (bench field): one tile per workgroup
+  static const uint32_t chunk_from = [] {
+    const char *e = getenv("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : 3u;
+  }();
+  if (pass < chunk_from) {
+    k_relax<RX_NW, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
+                                                         prev, cur, pf, max_iters, pass == 0 ? seed_labels : nullptr);
+  } else {
+    const int chunk = 4;
+    k_relax<RX_NW, true><<<(tx * ty + chunk - 1) / chunk, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted,
+                                                                              chunk, max_level, pass, prev, cur, pf, max_iters, nullptr);
+  }
   return hipGetLastError();
 }
 
