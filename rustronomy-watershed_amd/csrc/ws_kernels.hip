@@ -319,7 +319,8 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 //
 // Same forest as k_resolve, but resolved without iterating over launches:
 //   k_resolve_local  every tile builds the parent pointers of its pixels in LDS and collapses the
-//                    in-tile part of the forest by pointer jumping (log2(depth) rounds).  A pixel
+//                    in-tile part of the forest by pointer jumping (log2(depth) rounds; a pixel whose
+//                    parent is a seed -- about half of them on a random field -- takes no part).  A pixel
 //                    whose root is a seed of the tile gets that seed's colour; a pixel whose chain
 //                    leaves the tile gets a REFERENCE to the halo pixel where it leaves
 //                    (REF_BIT | global pixel index) instead of a colour.
@@ -332,33 +333,57 @@ constexpr uint32_t REF_BIT = 0x80000000u;
 
 typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 
+// Layout: thread t owns the 4 x 4 patch (t & 15, t >> 4) of the 64 x 64 tile, stamps / colours /
+// pointers in registers; global accesses are 16 B per lane and row.  The LDS tile has pitch RL_P = 72
+// and the patch grid starts at column 4, so that patch rows are 16-byte aligned (ds_*_b128); the halo
+// ring sits at rows 0 / 65 and columns 3 / 68.
+constexpr int RL_P = 72, RL_X0 = 4, RL_ROWS = TS + 2;
+constexpr uint32_t RL_FINAL = 0x8000u;          // pointer flag: the target is a root of the in-tile forest
+
 __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
                                                             uint32_t *ref_list, size_t ref_cap, uint32_t max_rounds) {
-  // One 66 x 66 LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
-  __shared__ __attribute__((aligned(16))) uint32_t sB[LP * LP];
+  // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
+  __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   __shared__ uint32_t s_flag[3];
   __shared__ uint32_t s_wave_refs[NTHREADS / 64], s_ref_base;
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, strip = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pc = tid & 15, pr = tid >> 4;
   const int x0 = tile_x * TS, y0 = tile_y * TS;
-  const int lx = lane + 1, ly0 = strip * STRIP + 1;
-  const int gx = x0 + lane, gy0 = y0 + strip * STRIP;
+  const int gx0 = x0 + pc * 4, gy0 = y0 + pr * 4;
+  const int lx0 = RL_X0 + pc * 4, ly0 = 1 + pr * 4;
   if (tid < 3) s_flag[tid] = 0;
 
-  // ---- loads: unconditional on clamped addresses (see ws_relax.hip).  Every thread owns the column
-  // strip (gx, gy0 .. gy0+15): stamps and painted colours of the strip stay in registers, rows are
-  // 256 B contiguous across the wave.
-  uint32_t K[STRIP], Lb[STRIP];
-  {
-    const int gxc = min(gx, W - 1);
+  // ---- loads: unconditional on clamped addresses (see ws_relax.hip)
+  uint32_t K[4][4], Lb[4][4];
+  const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(labels)) & 15u) == 0;
+  if (vec) {          // W % 4 == 0: a patch is wholly inside or wholly outside the plane in x
+    const int gxc = min(gx0, W - 4);
+    u32x4_r kv[4], lv[4];
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      const size_t g = (size_t)min(gy0 + i, H - 1) * W + gxc;
-      K[i] = keys[g];
-      Lb[i] = labels[g];
+    for (int r = 0; r < 4; ++r) {
+      const size_t g = (size_t)min(gy0 + r, H - 1) * W + gxc;
+      kv[r] = *reinterpret_cast<const u32x4_r *>(keys + g);
+      lv[r] = *reinterpret_cast<const u32x4_r *>(labels + g);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      K[r][0] = kv[r].x; K[r][1] = kv[r].y; K[r][2] = kv[r].z; K[r][3] = kv[r].w;
+      Lb[r][0] = lv[r].x; Lb[r][1] = lv[r].y; Lb[r][2] = lv[r].z; Lb[r][3] = lv[r].w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t g = (size_t)min(gy0 + r, H - 1) * W + min(gx0 + c, W - 1);
+        K[r][c] = keys[g];
+        Lb[r][c] = labels[g];
+      }
+  }
+  {
     // halo ring: thread t loads (top, bottom, left, right)[t & 63]
     const int side = tid >> 6, t = tid & 63;
     const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
@@ -366,61 +391,78 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     const uint32_t hv = keys[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
     const bool hok = hy >= 0 && hy < H && hx >= 0 && hx < W;
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      if (!(gy0 + i < H && gx < W)) { K[i] = KEY_INF; Lb[i] = 0u; }
-      sB[(ly0 + i) * LP + lx] = K[i];
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (!(gy0 + r < H && gx0 + c < W)) { K[r][c] = KEY_INF; Lb[r][c] = 0u; }
+      *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{K[r][0], K[r][1], K[r][2], K[r][3]};
     }
-    sB[(hy - (y0 - 1)) * LP + (hx - (x0 - 1))] = hok ? hv : KEY_INF;
+    sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = hok ? hv : KEY_INF;
   }
   __syncthreads();
 
-  // ---- parent pointer of every pixel of the strip: up/down neighbours are registers of this thread
-  uint32_t P[STRIP];
+  // ---- parent pointer of every pixel of the patch.  A pointer carries RL_FINAL when its target is a
+  // root of the in-tile forest (a seed, or a halo cell = where the chain leaves the tile): such a
+  // pixel never enters the jumping rounds.  Roots point at themselves.
+  uint32_t P[4][4];
+  uint32_t live = 0;                             // pixels whose pointer may still move
   {
-    const uint32_t k_above = sB[(ly0 - 1) * LP + lx], k_below = sB[(ly0 + STRIP) * LP + lx];
+    const u32x4_r up4 = *reinterpret_cast<const u32x4_r *>(&sB[(ly0 - 1) * RL_P + lx0]);
+    const u32x4_r dn4 = *reinterpret_cast<const u32x4_r *>(&sB[(ly0 + 4) * RL_P + lx0]);
+    const uint32_t up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+    uint32_t Lc[4], Rc[4];
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
-      const uint32_t k = K[i];
-      const int gy = gy0 + i;
-      uint32_t p = cell;
-      // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U (lib.rs:190, 245)
-      if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
-        const uint32_t d = i == STRIP - 1 ? k_below : K[i + 1];
-        const uint32_t r = sB[cell + 1], l = sB[cell - 1];
-        (void)k_above;      // "up" is the fall-through: at a fixpoint one of the four is earlier
-        p = d < k ? cell + LP : (r < k ? cell + 1 : (l < k ? cell - 1 : cell - LP));
+    for (int r = 0; r < 4; ++r) { Lc[r] = sB[(ly0 + r) * RL_P + lx0 - 1]; Rc[r] = sB[(ly0 + r) * RL_P + lx0 + 4]; }
+    const bool top_halo = pr == 0, bot_halo = pr == 15, left_halo = pc == 0, right_halo = pc == 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gy = gy0 + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gx = gx0 + c;
+        const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
+        const uint32_t k = K[r][c];
+        uint32_t p = cell | RL_FINAL;
+        // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U
+        // (lib.rs:190, 245); "up" is the fall-through: at a fixpoint one of the four is earlier
+        if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
+          const uint32_t d = r == 3 ? dn[c] : K[r + 1][c];
+          const uint32_t rr = c == 3 ? Rc[r] : K[r][c + 1];
+          const uint32_t l = c == 0 ? Lc[r] : K[r][c - 1];
+          const uint32_t u = r == 0 ? up[c] : K[r - 1][c];
+          const bool td = d < k, tr = rr < k, tl = l < k;
+          const uint32_t tgt = td ? cell + RL_P : (tr ? cell + 1 : (tl ? cell - 1 : cell - RL_P));
+          const uint32_t kp = td ? d : (tr ? rr : (tl ? l : u));
+          const bool halo = td ? (r == 3 && bot_halo) : (tr ? (c == 3 && right_halo) : (tl ? (c == 0 && left_halo) : (r == 0 && top_halo)));
+          const bool fin = kp == 0u || halo;
+          p = tgt | (fin ? RL_FINAL : 0u);
+          if (!fin) live |= 1u << (r * 4 + c);
+        }
+        P[r][c] = p;
       }
-      P[i] = p;
     }
   }
   __syncthreads();                               // every stamp has been read: the tile becomes pointers
-  {
-    const int side = tid >> 6, t = tid & 63;     // halo cells are roots (self pointers)
-    const int ly = side == 0 ? 0 : (side == 1 ? LP - 1 : t + 1), lxx = side == 2 ? 0 : (side == 3 ? LP - 1 : t + 1);
-    sB[ly * LP + lxx] = (uint32_t)(ly * LP + lxx);
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = P[i];
-  }
+  for (int r = 0; r < 4; ++r)
+    *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{P[r][0], P[r][1], P[r][2], P[r][3]};
   __syncthreads();
 
-  uint32_t live = 0;                             // pixels whose pointer may still move
+  for (uint32_t it = 0;; ++it) {                 // pointer jumping: P <- P(P), until P's target is a root
 #pragma unroll
-  for (int i = 0; i < STRIP; ++i) live |= (P[i] != (uint32_t)((ly0 + i) * LP + lx)) ? (1u << i) : 0u;
-  for (uint32_t it = 0;; ++it) {                 // pointer jumping: P <- P(P)
-    bool changed = false;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      if ((live >> i) & 1u) {
-        const uint32_t q = P[i];
-        const uint32_t g = sB[q];
-        if (g != q) { P[i] = g; sB[(ly0 + i) * LP + lx] = g; changed = true; }
-        else live &= ~(1u << i);                 // q is a root: this pixel is done
+      for (int c = 0; c < 4; ++c) {
+        if ((live >> (r * 4 + c)) & 1u) {
+          const uint32_t g = sB[P[r][c]];        // live pointers carry no flag: the value is the cell index
+          P[r][c] = g;
+          sB[(ly0 + r) * RL_P + lx0 + c] = g;
+          if (g & RL_FINAL) live &= ~(1u << (r * 4 + c));
+        }
       }
-    }
     // one barrier per round: flag slot it % 3 (see k_relax)
     const uint32_t slot = it % 3;
-    if (__builtin_amdgcn_ballot_w64(changed) != 0 && lane == 0) s_flag[slot] = 1;
+    if (__builtin_amdgcn_ballot_w64(live != 0) != 0 && lane == 0) s_flag[slot] = 1;
     __syncthreads();
     const bool again = s_flag[slot] != 0;
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
@@ -429,22 +471,33 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
   // every pointer is final and in registers: the tile now becomes the painted colours, so that the
   // colour of an in-tile root (a seed) is one LDS read
 #pragma unroll
-  for (int i = 0; i < STRIP; ++i) sB[(ly0 + i) * LP + lx] = Lb[i];
+  for (int r = 0; r < 4; ++r)
+    *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{Lb[r][0], Lb[r][1], Lb[r][2], Lb[r][3]};
   __syncthreads();
 
   uint32_t refmask = 0;                          // pixels whose chain leaves the tile
-  if (gx < W) {
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i) {
-      const int gy = gy0 + i;
-      const uint32_t cell = (uint32_t)((ly0 + i) * LP + lx);
-      const uint32_t r = P[i];
-      if (r != cell && gy < H) {
-        const int rly = (int)(r / LP), rlx = (int)(r - (uint32_t)rly * LP);
-        const bool inside = rly >= 1 && rly <= TS && rlx >= 1 && rlx <= TS;
-        const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - 1 + rlx);
-        labels[(size_t)gy * W + gx] = inside ? sB[r] : (REF_BIT | (uint32_t)rg);
-        if (!inside) refmask |= 1u << i;
+  for (int r = 0; r < 4; ++r) {
+    const int gy = gy0 + r;
+    uint32_t out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
+      const uint32_t t = P[r][c] & (RL_FINAL - 1u);
+      const int rly = (int)(t / RL_P), rlx = (int)(t - (uint32_t)rly * RL_P);
+      const bool inside = rly >= 1 && rly <= TS && rlx >= RL_X0 && rlx < RL_X0 + TS;
+      const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - RL_X0 + rlx);
+      const uint32_t col = sB[inside ? t : cell];
+      out[c] = t == cell ? Lb[r][c] : (inside ? col : (REF_BIT | (uint32_t)rg));
+      if (t != cell && !inside && gy < H && gx0 + c < W) refmask |= 1u << (r * 4 + c);
+    }
+    if (gy < H) {
+      if (vec) {
+        if (gx0 < W) *reinterpret_cast<u32x4_r *>(labels + (size_t)gy * W + gx0) = u32x4_r{out[0], out[1], out[2], out[3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (gx0 + c < W && (P[r][c] & (RL_FINAL - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)) labels[(size_t)gy * W + gx0 + c] = out[c];
       }
     }
   }
@@ -456,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     const uint32_t v = __shfl_up(incl, off, 64);
     if (lane >= off) incl += v;
   }
-  if (lane == 63) s_wave_refs[strip] = incl;
+  if (lane == 63) s_wave_refs[wave] = incl;
   __syncthreads();
   if (tid == 0) {
     uint32_t total = 0;
@@ -466,11 +519,11 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
   __syncthreads();
   if (refmask) {
     uint32_t pos = s_ref_base + incl - cnt;
-    for (int k = 0; k < strip; ++k) pos += s_wave_refs[k];
+    for (int k = 0; k < wave; ++k) pos += s_wave_refs[k];
     uint32_t *dst = ref_list + (size_t)(blockIdx.x % NSTRIPE) * ref_cap;
 #pragma unroll
-    for (int i = 0; i < STRIP; ++i)
-      if ((refmask >> i) & 1u) dst[pos++] = (uint32_t)((size_t)(gy0 + i) * W + gx);
+    for (int i = 0; i < 16; ++i)
+      if ((refmask >> i) & 1u) dst[pos++] = (uint32_t)((size_t)(gy0 + (i >> 2)) * W + gx0 + (i & 3));
   }
 }
 
