@@ -183,33 +183,55 @@ int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *
 
 // ---- fused engine ------------------------------------------------------------------------
 
-// Runs `launch(pass)` until a pass reports zero changed tile edges.  The host stays
-// PASS_LOOKAHEAD passes ahead of the flag it reads (a pass launched after convergence exits in
-// every tile at once, ~5 us), so the stream never waits for a host round trip between passes.
-constexpr uint32_t PASS_LOOKAHEAD = 3;
+// Runs `launch(pass)` until a pass reports zero changed tile edges.  Passes are launched in GROUPS:
+// one event record + one flag read-back (on a side stream) per group, not per pass -- an event
+// record between two dependent kernels costs ~10 us of dependency gap on this stack, a pass that
+// has nothing to do ~4 us.  The host stays one group ahead of the flags it reads, so the stream
+// never waits for a host round trip.  Flag slots live in a ring of COUNTER_RING passes (pass q clears
+// the slot of pass q + 1): first_group + GROUP passes in flight must stay below it.
+constexpr uint32_t PASS_GROUP = 2;
 template <class F>
-int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch) {
-  HIP_TRY(c, hipMemsetAsync(c->stamps.p, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_EDGE, 0, COUNTER_RING * FLAG_SLOT * sizeof(uint32_t), c->stream));
-  uint32_t pass = 0;
-  for (;; ++pass) {
-    HIP_TRY(c, launch(pass));
-    const int slot = pass % COUNTER_RING;
-    // the flag read-back rides a side stream: the next pass never queues behind a copy
-    HIP_TRY(c, hipEventRecord(c->kern_ev[slot], c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[slot], 0));
-    HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_EDGE + slot * FLAG_SLOT], d_flags + FLAG_EDGE + slot * FLAG_SLOT,
-                              FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
-    HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->copy_stream));
-    if (pass >= PASS_LOOKAHEAD) {
-      const int prev = (pass - PASS_LOOKAHEAD) % COUNTER_RING;
-      HIP_TRY(c, hipEventSynchronize(c->ring_ev[prev]));
-      if (!slot_nonzero(&c->pinned[FLAG_EDGE + prev * FLAG_SLOT])) break;
+int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch, bool zeroed = false,
+              uint32_t first_group = 2) {
+  static_assert(5 + PASS_GROUP < COUNTER_RING, "groups in flight must fit the flag ring");
+  if (first_group > 5) first_group = 5;
+  if (!zeroed) {        // the tile-edge stamps and the convergence ring start at zero
+    HIP_TRY(c, hipMemsetAsync(c->stamps.p, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_EDGE, 0, COUNTER_RING * FLAG_SLOT * sizeof(uint32_t), c->stream));
+  }
+  uint32_t launched = 0, group = 0;
+  struct Group { uint32_t lo, hi, ev; };
+  auto launch_group = [&](uint32_t count, Group *g) -> int {
+    g->lo = launched;
+    for (uint32_t i = 0; i < count; ++i) HIP_TRY(c, launch(launched++));
+    g->hi = launched;
+    g->ev = group++ % COUNTER_RING;
+    // the flag read-back rides a side stream: the next group never queues behind a copy
+    HIP_TRY(c, hipEventRecord(c->kern_ev[g->ev], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g->ev], 0));
+    for (uint32_t p = g->lo; p < g->hi; ++p) {
+      const int slot = p % COUNTER_RING;
+      HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_EDGE + slot * FLAG_SLOT], d_flags + FLAG_EDGE + slot * FLAG_SLOT,
+                                FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
     }
+    HIP_TRY(c, hipEventRecord(c->ring_ev[g->ev], c->copy_stream));
+    return WS_OK;
+  };
+  Group done{}, ahead{};
+  int rc;
+  if ((rc = launch_group(first_group, &done))) return rc;
+  for (;;) {
+    if ((rc = launch_group(PASS_GROUP, &ahead))) return rc;
+    HIP_TRY(c, hipEventSynchronize(c->ring_ev[done.ev]));
+    bool converged = false;
+    for (uint32_t p = done.lo; p < done.hi && !converged; ++p)
+      converged = !slot_nonzero(&c->pinned[FLAG_EDGE + (p % COUNTER_RING) * FLAG_SLOT]);
+    if (converged) break;
+    done = ahead;
   }
   // later work on the main stream may reuse the flag words: order it after the last read-back
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring_ev[pass % COUNTER_RING], 0));
-  *passes_out = pass + 1;
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring_ev[ahead.ev], 0));
+  *passes_out = launched;
   return WS_OK;
 }
 
@@ -227,9 +249,8 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
 
   {
     Span sp(c, KC_OTHER);
-    HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
-    if (c->profiling) HIP_TRY(c, hipMemsetAsync(flags + FLAG_STATS, 0, 2 * FLAG_SLOT * sizeof(uint32_t), c->stream));
+    // one launch clears the label plane, the relaxation's tile-edge stamps and every flag word
+    HIP_TRY(c, zero3(c->stream, d_labels, n, stamps, relax_tiles(ph, pw) * 4 * 2, flags, FLAG_WORDS));
     // stamps are not touched here: relaxation pass 0 derives them from the painted label plane
     HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, nullptr, flags + FLAG_SEED_ERR));
   }
@@ -239,7 +260,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters, d_labels);
-  });
+  }, true, 5);
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
 
@@ -247,7 +268,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
     if ((rc = ensure(c, c->refs, NSTRIPE * resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters));
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters, true));
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {

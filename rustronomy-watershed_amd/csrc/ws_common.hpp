@@ -42,6 +42,7 @@ struct PassFlags {
 
 // --- launch wrappers (ws_kernels.hip) ---------------------------------------------------
 hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
+hipError_t zero3(hipStream_t s, uint32_t *a, size_t na, uint32_t *b, size_t nb, uint32_t *c, size_t nc);   // one launch
 hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst);
 hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
@@ -64,7 +65,8 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 // ref_count: FLAG_SLOT words of striped counters; ref_list: NSTRIPE * resolve_ref_capacity(h, w) words
 size_t resolve_ref_capacity(int h, int w);
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds = 0xFFFFFFFFu);
+                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds = 0xFFFFFFFFu,
+                              bool ref_count_zeroed = false);
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

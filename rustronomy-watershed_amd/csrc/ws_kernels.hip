@@ -5,6 +5,8 @@
 // (lanes run along x) and wave-level reductions for convergence.
 #include "ws_common.hpp"
 
+#include <algorithm>
+
 namespace wsk {
 
 // ---------------------------------------------------------------- small utilities ----
@@ -19,6 +21,30 @@ hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
   k_fill_u32<<<blocks, 256, 0, s>>>(p, n, v);
+  return hipGetLastError();
+}
+
+// Zeroes a plane and two small arrays in ONE launch: the prologue of a fused transform clears the
+// label plane, the tile-edge stamps and the flag words, and every separate memset is a launch plus
+// a dependency gap (~10 us each).
+typedef uint32_t u32x4_z __attribute__((ext_vector_type(4)));
+__global__ void k_zero3(uint32_t *a, size_t na, uint32_t *b, size_t nb, uint32_t *c, size_t nc) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  size_t head = (size_t)((16u - (unsigned)(reinterpret_cast<uintptr_t>(a) & 15u)) & 15u) >> 2;   // words up to 16-byte alignment
+  if (head > na) head = na;
+  const size_t body = (na - head) >> 2;
+  u32x4_z *a4 = reinterpret_cast<u32x4_z *>(a + head);
+  for (size_t i = tid; i < body; i += step) a4[i] = u32x4_z{0u, 0u, 0u, 0u};
+  if (tid < head) a[tid] = 0u;
+  for (size_t i = head + body * 4 + tid; i < na; i += step) a[i] = 0u;
+  for (size_t i = tid; i < nb; i += step) b[i] = 0u;
+  for (size_t i = tid; i < nc; i += step) c[i] = 0u;
+}
+
+hipError_t zero3(hipStream_t s, uint32_t *a, size_t na, uint32_t *b, size_t nb, uint32_t *c, size_t nc) {
+  const size_t most = std::max(std::max(na / 4, nb), std::max(nc, (size_t)1));
+  const int blocks = (int)std::min<size_t>((most + 255) / 256, 4096);
+  k_zero3<<<blocks, 256, 0, s>>>(a, na, b, nb, c, nc);
   return hipGetLastError();
 }
 
@@ -548,12 +574,12 @@ size_t resolve_ref_capacity(int h, int w) {
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds) {
+                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds, bool ref_count_zeroed) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t cap = resolve_ref_capacity(h, w);
-  hipError_t e = hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
+  hipError_t e = ref_count_zeroed ? hipSuccess : hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
   k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds);
   e = hipGetLastError();
