@@ -58,6 +58,7 @@ struct ws_ctx {
   std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
+  bool misc_clean = false;      // the three error words of the flag block are known to be zero
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
 };
 
@@ -79,6 +80,7 @@ constexpr int FLAG_WORDS = FLAG_MISC + 16;
 
 PassFlags make_pf(ws_ctx *c) {
   uint32_t *f = (uint32_t *)c->flags.p;
+  c->misc_clean = false;      // the overflow word may be written
   return PassFlags{f + FLAG_EDGE, f + FLAG_ANY, f + FLAG_OVERFLOW, c->profiling ? f + FLAG_STATS : nullptr};
 }
 
@@ -249,10 +251,16 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
 
   {
     Span sp(c, KC_OTHER);
-    // one launch clears the label plane, the relaxation's tile-edge stamps and every flag word
-    HIP_TRY(c, zero3(c->stream, d_labels, n, stamps, relax_tiles(ph, pw) * 4 * 2, flags, FLAG_WORDS));
-    // stamps are not touched here: relaxation pass 0 derives them from the painted label plane
-    HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, d_labels, nullptr, flags + FLAG_SEED_ERR));
+    // The three error words (ring overflow, seed out of bounds, list unsorted) are only ever RAISED by
+    // kernels; they are known to be zero after a transform that read all three back as zero, and
+    // cleared here otherwise -- the painting kernel cannot clear words it may have to raise.
+    if (!c->misc_clean) HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
+    c->misc_clean = false;
+    // One pass over the label plane paints the seeds (colour i + 1, later duplicates win) and zeroes
+    // everything else; the same launch clears the relaxation's tile-edge stamps and the striped flag
+    // words.  The arrival-stamp plane is not touched: relaxation pass 0 derives it from the labels.
+    HIP_TRY(c, paint_labels(c->stream, d_seeds, n_seeds, ph, pw, d_labels, flags + FLAG_SEED_ERR, stamps,
+                            relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
   }
   if (n == 0) return WS_OK;
 
@@ -278,7 +286,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
     if (rc) return rc;
   }
   c->stats.launches_resolve = c->stats.resolve_passes;
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 3 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
   if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
     HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_STATS], flags + FLAG_STATS, 2 * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -292,6 +300,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   }
   if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
   if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+  c->misc_clean = c->pinned[FLAG_UNSORTED] == 0;
   c->have_keys = true;
   c->last_h = ph;
   c->last_w = pw;
@@ -313,6 +322,7 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   c->have_keys = false;
   HIP_TRY(c, hipMemsetAsync(cur, 0, n * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
+  c->misc_clean = false;
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds, nullptr, n_seeds, ph, pw, cur, nullptr, flags + FLAG_SEED_ERR));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
@@ -724,6 +734,7 @@ int ws_block_init(ws_ctx *c, size_t h, size_t w, const uint32_t *d_seeds_rc, con
   HIP_TRY(c, fill_u32(c->stream, d_keys, n, KEY_INF));
   if (n) HIP_TRY(c, hipMemsetAsync(d_labels, 0, n * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
+  c->misc_clean = false;
   HIP_TRY(c, scatter_seeds(c->stream, d_seeds_rc, d_colours, n_seeds, (int)h, (int)w, d_labels, d_keys, flags + FLAG_SEED_ERR));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -47,6 +47,8 @@ hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h
 hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag);
+hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
+                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);

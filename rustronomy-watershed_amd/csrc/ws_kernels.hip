@@ -6,6 +6,7 @@
 #include "ws_common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace wsk {
 
@@ -138,6 +139,141 @@ hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   k_scatter_fixup<<<blocks, 256, 0, s>>>(seeds_rc, colours, n, ph, pw, labels, err_flag + 1);
+  return hipGetLastError();
+}
+
+// ---- painting a whole label plane in one pass ------------------------------------------------
+//
+// memset + scatter writes the plane twice (the scatter's 4-byte stores dirty nearly every line of it
+// again).  When the seed list is sorted by pixel index -- what find_local_minima returns -- a wave can
+// instead FIND the seeds of its own 4096-pixel chunk (64-ary lower bound: 4 dependent probes for
+// 7 M seeds) and walk down the list from there: per 256-pixel segment the seeds' colours are dropped
+// into a 1 KiB LDS row and the segment is written once, 16 B per lane.
+// Nothing is assumed: every wave also checks a slice of the list for order (and every seed for
+// bounds); if any consecutive pair is out of order `unsorted` is raised and k_scatter_fixup, which
+// runs next, raises every seed pixel to its largest seed index with atomicMax.  That is exact
+// whatever the wave walks found, because a painted pixel always holds 0 or the colour of one of its
+// own seeds.
+constexpr int PAINT_SEG = 256;       // pixels per step of a wave: one 16-byte store per lane
+constexpr int PAINT_STEPS = 16;      // consecutive segments per wave: one search, then a walk down the list
+constexpr int PAINT_WAVES = 4;       // waves per workgroup
+
+__device__ __forceinline__ unsigned long long seed_pos(uint2 rc, int pw) { return (unsigned long long)rc.x * (unsigned)pw + rc.y; }
+
+__global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
+                                                                  uint32_t *labels, size_t npx, size_t nchunk, int steps,
+                                                                  uint32_t *err_flag, uint32_t *unsorted_flag,
+                                                                  uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][PAINT_SEG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
+  {   // side job: the small arrays the transform wants zeroed (tile-edge stamps, flag words)
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
+    for (size_t i = tid; i < n_zero_b; i += step) zero_b[i] = 0u;
+  }
+  const size_t chunk = (size_t)blockIdx.x * PAINT_WAVES + wave;       // PAINT_STEPS consecutive segments
+  if (chunk >= nchunk) return;
+  uint32_t *row = sRow[wave];
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0;
+
+  // ---- order and bounds of this wave's slice of the list (independent loads, issued first)
+  {
+    const size_t per = (n + nchunk - 1) / nchunk;
+    const size_t lo = chunk * per, hi = lo + per < n ? lo + per : n;
+    for (size_t j = lo + lane; j < hi; j += 64) {
+      const uint2 a = seeds[j];
+      if (a.x >= (uint32_t)ph || a.y >= (uint32_t)pw) atomicExch(err_flag, 1u);
+      if (j + 1 < n && seed_pos(seeds[j + 1], pw) < seed_pos(a, pw)) *unsorted_flag = 1u;
+    }
+  }
+
+  // ---- 64-ary lower bound of the chunk start: smallest j with pos(j) >= p0
+  unsigned long long p0 = (unsigned long long)chunk * (unsigned long long)(PAINT_SEG * steps);
+  size_t lo = 0, hi = n;
+  while (hi - lo > 64) {
+    const size_t step = (hi - lo + 63) / 64;
+    const size_t j = lo + (size_t)lane * step;
+    const bool before = j < hi && seed_pos(seeds[j], pw) < p0;
+    const int c = __popcll(__builtin_amdgcn_ballot_w64(before));
+    if (c == 0) { hi = lo; break; }
+    const size_t nlo = lo + (size_t)(c - 1) * step + 1, nhi = lo + (size_t)c * step;
+    hi = nhi < hi ? nhi : hi;
+    lo = nlo;
+  }
+  if (hi > lo) {
+    const size_t j = lo + lane;
+    const bool before = j < hi && seed_pos(seeds[j], pw) < p0;
+    lo += __popcll(__builtin_amdgcn_ballot_w64(before));
+  }
+
+  // ---- walk: the list from `lo` on is cut into fixed windows of 64 seeds, one per lane; `off` is the
+  // first lane of the current window that has not been painted yet.  A segment paints the run of
+  // in-segment seeds from `off` on, across as many windows as it takes.  The window after the current
+  // one is always in flight already, so no load latency is exposed after the first.
+  size_t wbase = lo;                                   // list index of lane 0 of the current window
+  int off = 0;
+  uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
+  if (n) {
+    cur = seeds[wbase + lane < n ? wbase + lane : n - 1];
+    nxt = seeds[wbase + 64 + lane < n ? wbase + 64 + lane : n - 1];
+  }
+  for (int sgm = 0; sgm < steps && p0 < npx; ++sgm, p0 += PAINT_SEG) {
+    const unsigned long long p1 = p0 + PAINT_SEG < npx ? p0 + PAINT_SEG : npx;
+    *reinterpret_cast<u32x4_z *>(&row[lane * 4]) = u32x4_z{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the zeroed row before the colours
+    for (;;) {
+      const size_t j = wbase + lane;
+      const unsigned long long pos = seed_pos(cur, pw);
+      const bool ok = j < n && pos >= p0 && pos < p1;
+      // lanes below `off` count as done; the run ends at the first lane from `off` on that is not in the segment
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(ok) | ((1ull << off) - 1ull);
+      const int end = m == ~0ull ? 64 : __builtin_ctzll(~m);
+      if (lane >= off && lane < end && cur.x < (uint32_t)ph && cur.y < (uint32_t)pw)
+        atomicMax(&row[(uint32_t)(pos - p0)], (uint32_t)(j + 1));
+      off = end;
+      if (off < 64) break;
+      wbase += 64;                                       // window exhausted: the prefetched one becomes current
+      off = 0;
+      cur = nxt;
+      if (n) nxt = seeds[wbase + 64 + lane < n ? wbase + 64 + lane : n - 1];
+      if (wbase >= n) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // one 16-byte store per lane
+    const u32x4_z v = *reinterpret_cast<const u32x4_z *>(&row[lane * 4]);
+    const unsigned long long q = p0 + (unsigned long long)lane * 4;
+    if (q + 4 <= npx && vec_ok) {
+      *reinterpret_cast<u32x4_z *>(labels + q) = v;
+    } else {
+      const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (q + k < npx) labels[q + k] = e[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the row is read before it is zeroed again
+  }
+}
+
+// Paints colour i + 1 at seed i over a zeroed plane, later duplicates winning (lib.rs:1672-1677), in
+// one pass over the plane plus a fix-up that only works when the list is not sorted.  Also zeroes two
+// small arrays.  err_flag points at two consecutive words, as for scatter_seeds; they must be zero.
+hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
+                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  const size_t npx = (size_t)ph * pw;
+  static const int steps = [] {
+    const char *e = getenv("WS_PAINT_STEPS");      // tuning knob, tools/ only
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : PAINT_STEPS;
+  }();
+  const size_t per_wave = (size_t)PAINT_SEG * steps;
+  const size_t nchunk = (npx + per_wave - 1) / per_wave;
+  const size_t blocks = std::max<size_t>((nchunk + PAINT_WAVES - 1) / PAINT_WAVES, 1);
+  k_paint_sorted<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, labels, npx, nchunk, steps, err_flag, err_flag + 1,
+                                                              zero_a, n_zero_a, zero_b, n_zero_b);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || n == 0) return e;
+  const int fb = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  k_scatter_fixup<<<fb, 256, 0, s>>>(seeds_rc, nullptr, n, ph, pw, labels, err_flag + 1);
   return hipGetLastError();
 }
 

@@ -275,3 +275,32 @@ def test_full_size_fixpoint_properties(pkg, size):
     # in test_device_path_matches_host_path; here also check idempotence of a second run
     again = eng.segment(img, seeds)
     assert bool((again == labels).all())
+
+
+# ---- seed painting: one-pass path for sorted lists, fix-up for everything else (lib.rs:1672-1677) ----
+
+@pytest.mark.parametrize("shape", [(700, 1100), (1023, 517), (64, 8)])
+def test_seed_painting_sorted_duplicated_and_shuffled_lists(pkg, shape):
+    img = cases.field(*shape, 21)
+    base = ol.find_local_minima(img)                       # row-major, strictly increasing
+    rng = np.random.default_rng(5)
+    ws = _seg(pkg, pkg.ENGINE_FUSED)
+    variants = {
+        "sorted": base,
+        "sorted_adjacent_duplicates": np.repeat(base, 1 + (np.arange(len(base)) % 5 == 0), axis=0),
+        "shuffled": base[rng.permutation(len(base))],
+        "one_swap_at_the_end": np.concatenate([base[:-2], base[-1:], base[-2:-1]]),
+        "shuffled_with_duplicates": np.concatenate([base, base[::7]])[rng.permutation(len(base) + len(base[::7]))],
+        "border_and_corner_seeds": np.concatenate([np.array([[0, 0], [0, shape[1] - 1]], np.uint64), base,
+                                                   np.array([[shape[0] - 1, 0], [shape[0] - 1, shape[1] - 1]], np.uint64)]),
+    }
+    for name, seeds in variants.items():
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        got = ws.transform(img, seeds)
+        want = ol.segment_arrival(img, seeds)
+        assert got.shape == want.shape and (got == want).all(), name
+    # a seed outside the plane anywhere in a sorted list is still reported (the reference panics: lib.rs:1676)
+    bad = np.concatenate([base[: len(base) // 2], np.array([[shape[0], 0]], np.uint64), base[len(base) // 2:]])
+    with pytest.raises(IndexError):
+        ws.transform(img, bad)
+    assert (ws.transform(img, base) == ol.segment_arrival(img, base)).all()         # and the context recovers
