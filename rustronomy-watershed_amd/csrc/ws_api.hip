@@ -44,7 +44,7 @@ struct ws_ctx {
   ws_stats stats{};
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
-  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs;
+  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab;
   uint32_t *pinned = nullptr;      // COUNTER_RING + 4 words of pinned host memory
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
@@ -58,7 +58,8 @@ struct ws_ctx {
   std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
-  bool misc_clean = false;      // the three error words of the flag block are known to be zero
+  bool misc_clean = false;      // the error words of the flag block (FLAG_NERR of them) are known to be zero
+  bool expect_sorted = true;    // the last seed list was strictly increasing: try the side-table form first
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
 };
 
@@ -72,10 +73,12 @@ constexpr int FLAG_REFS = FLAG_STATS + 2 * FLAG_SLOT;        // [FLAG_SLOT] stri
 constexpr int FLAG_MISC = FLAG_REFS + FLAG_SLOT;
 constexpr int FLAG_OVERFLOW = FLAG_MISC + 0;
 constexpr int FLAG_SEED_ERR = FLAG_MISC + 1;
-constexpr int FLAG_UNSORTED = FLAG_MISC + 2;                 // seed list not strictly increasing
-static_assert(FLAG_UNSORTED == FLAG_SEED_ERR + 1, "scatter_seeds writes both words through one pointer");
-constexpr int FLAG_TOTAL = FLAG_MISC + 3;                    // minima total
-constexpr int FLAG_SWEEP = FLAG_MISC + 4;                    // sweep engine: tiles coloured in the last step
+constexpr int FLAG_UNSORTED = FLAG_MISC + 2;                 // seed list not sorted by pixel index
+constexpr int FLAG_NONSTRICT = FLAG_MISC + 3;                // seed list not STRICTLY increasing (painting kernels only)
+static_assert(FLAG_UNSORTED == FLAG_SEED_ERR + 1 && FLAG_NONSTRICT == FLAG_SEED_ERR + 2, "the seed kernels write these words through one pointer");
+constexpr int FLAG_NERR = 4;                                 // OVERFLOW .. NONSTRICT: raised by kernels, never cleared by them
+constexpr int FLAG_TOTAL = FLAG_MISC + 4;                    // minima total
+constexpr int FLAG_SWEEP = FLAG_MISC + 5;                    // sweep engine: tiles coloured in the last step
 constexpr int FLAG_WORDS = FLAG_MISC + 16;
 
 PassFlags make_pf(ws_ctx *c) {
@@ -237,37 +240,53 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   return WS_OK;
 }
 
-int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
-              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels) {
+// Seeds reach the kernels in one of two forms.  TABLES: a strictly increasing list (what
+// find_local_minima returns) is turned into one bit per pixel plus a list index per 32-pixel word
+// (seed_tables), 16 MiB at 8192^2; relaxation pass 0 reads the bits, the resolve kernel computes seed
+// colours from both and writes the label plane exactly once.  PAINTED: any list -- the label plane is
+// painted first (paint_labels) and read back twice.  Whether a list is strictly increasing is only
+// known on the device, so the choice is a prediction: the context tries TABLES while the previous
+// list was strictly increasing; a wrong guess is detected by the table builder itself
+// (FLAG_NONSTRICT), costs one wasted transform, and flips the prediction.
+int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
+                   const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted) {
   const size_t n = (size_t)ph * pw;
   const size_t ntiles = (size_t)tiles_of(pw) * tiles_of(ph);
+  const size_t nwords = (n + 31) / 32;
   int rc;
   if ((rc = ensure(c, c->keys, (n ? n : 1) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->stamps, std::max(ntiles, relax_tiles(ph, pw)) * 4 * 2 * sizeof(uint32_t)))) return rc;
+  if (tables && (rc = ensure(c, c->seed_tab, (nwords ? nwords : 1) * 2 * sizeof(uint32_t)))) return rc;
   uint32_t *keys = (uint32_t *)c->keys.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
   uint32_t *stamps = (uint32_t *)c->stamps.p;
+  uint32_t *seed_mask = tables ? (uint32_t *)c->seed_tab.p : nullptr, *word_base = tables ? seed_mask + nwords : nullptr;
   c->have_keys = false;
+  *mispredicted = false;
 
   {
     Span sp(c, KC_OTHER);
-    // The three error words (ring overflow, seed out of bounds, list unsorted) are only ever RAISED by
-    // kernels; they are known to be zero after a transform that read all three back as zero, and
-    // cleared here otherwise -- the painting kernel cannot clear words it may have to raise.
-    if (!c->misc_clean) HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, 3 * sizeof(uint32_t), c->stream));
+    // The error words (ring overflow, seed out of bounds, list unsorted / not strict) are only ever
+    // RAISED by kernels; they are known to be zero after a transform that read them back as zero, and
+    // cleared here otherwise -- the seed kernel cannot clear words it may have to raise.
+    if (!c->misc_clean) HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, FLAG_NERR * sizeof(uint32_t), c->stream));
     c->misc_clean = false;
-    // One pass over the label plane paints the seeds (colour i + 1, later duplicates win) and zeroes
-    // everything else; the same launch clears the relaxation's tile-edge stamps and the striped flag
-    // words.  The arrival-stamp plane is not touched: relaxation pass 0 derives it from the labels.
-    HIP_TRY(c, paint_labels(c->stream, d_seeds, n_seeds, ph, pw, d_labels, flags + FLAG_SEED_ERR, stamps,
-                            relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
+    // The same launch clears the relaxation's tile-edge stamps and the striped flag words.  The
+    // arrival-stamp plane is not touched: relaxation pass 0 derives it from the seeds.
+    if (tables)
+      HIP_TRY(c, seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
+                             relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
+    else      // one pass over the label plane paints the seeds (colour i + 1, later duplicates win), zero elsewhere
+      HIP_TRY(c, paint_labels(c->stream, d_seeds, n_seeds, ph, pw, d_labels, flags + FLAG_SEED_ERR, stamps,
+                              relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
   }
   if (n == 0) return WS_OK;
 
   const PassFlags pf = make_pf(c);
   rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
-    return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters, d_labels);
+    return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
+                      tables ? seed_mask : d_labels, tables);
   }, true, 5);
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
@@ -276,7 +295,8 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
     if ((rc = ensure(c, c->refs, NSTRIPE * resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters, true));
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters, true,
+                                  seed_mask, word_base));
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
@@ -286,7 +306,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
     if (rc) return rc;
   }
   c->stats.launches_resolve = c->stats.resolve_passes;
-  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, 3 * sizeof(uint32_t),
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, FLAG_NERR * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, c->stream));
   if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
     HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_STATS], flags + FLAG_STATS, 2 * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -299,12 +319,28 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  c->expect_sorted = c->pinned[FLAG_NONSTRICT] == 0;
+  if (tables && !c->expect_sorted) {      // the tables describe some other list: nothing computed from them counts
+    *mispredicted = true;
+    return WS_OK;
+  }
   if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
-  c->misc_clean = c->pinned[FLAG_UNSORTED] == 0;
+  c->misc_clean = c->pinned[FLAG_UNSORTED] == 0 && c->pinned[FLAG_NONSTRICT] == 0;
   c->have_keys = true;
   c->last_h = ph;
   c->last_w = pw;
   return WS_OK;
+}
+
+int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
+              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels) {
+  // the side-table form needs nibble-aligned patch rows (W % 4 == 0) and the two-launch resolve
+  static const bool no_tables = getenv("WS_NO_SEED_TABLES") != nullptr;      // A/B knob for tools/
+  const bool can_tables = !no_tables && (pw & 3) == 0 && (size_t)ph * pw < 0x80000000ull && n_seeds > 0;
+  bool mispredicted = false;
+  int rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, can_tables && c->expect_sorted, &mispredicted);
+  if (rc == WS_OK && mispredicted) rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, false, &mispredicted);
+  return rc;
 }
 
 // ---- sweep engine ------------------------------------------------------------------------
@@ -528,7 +564,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux,
-                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs})
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -49,6 +49,8 @@ hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag);
 hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
                         uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
+hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
+                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);
@@ -57,7 +59,8 @@ hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *l
 size_t relax_tiles(int h, int w);
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels = nullptr);   // non-null: pass 0 derives the stamps from this label plane
+                      const uint32_t *seed_labels = nullptr,    // non-null: pass 0 derives the stamps from this label plane
+                      bool seed_bits = false);                  // ... which is one bit per pixel (seed_tables) instead
 
 // label resolve, iterative form (row blocks of a tiled field, planes >= 2^31 pixels): 64x64 tiles
 size_t resolve_tiles(int h, int w);
@@ -68,7 +71,8 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 size_t resolve_ref_capacity(int h, int w);
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
                               uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds = 0xFFFFFFFFu,
-                              bool ref_count_zeroed = false);
+                              bool ref_count_zeroed = false,
+                              const uint32_t *seed_mask = nullptr, const uint32_t *word_base = nullptr);   // seed_tables() form
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

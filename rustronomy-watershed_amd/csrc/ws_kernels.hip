@@ -160,36 +160,26 @@ constexpr int PAINT_WAVES = 4;       // waves per workgroup
 
 __device__ __forceinline__ unsigned long long seed_pos(uint2 rc, int pw) { return (unsigned long long)rc.x * (unsigned)pw + rc.y; }
 
-__global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
-                                                                  uint32_t *labels, size_t npx, size_t nchunk, int steps,
-                                                                  uint32_t *err_flag, uint32_t *unsorted_flag,
-                                                                  uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
-  __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][PAINT_SEG];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
-  {   // side job: the small arrays the transform wants zeroed (tile-edge stamps, flag words)
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
-    for (size_t i = tid; i < n_zero_b; i += step) zero_b[i] = 0u;
-  }
-  const size_t chunk = (size_t)blockIdx.x * PAINT_WAVES + wave;       // PAINT_STEPS consecutive segments
-  if (chunk >= nchunk) return;
-  uint32_t *row = sRow[wave];
-  const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0;
-
-  // ---- order and bounds of this wave's slice of the list (independent loads, issued first)
-  {
-    const size_t per = (n + nchunk - 1) / nchunk;
-    const size_t lo = chunk * per, hi = lo + per < n ? lo + per : n;
-    for (size_t j = lo + lane; j < hi; j += 64) {
-      const uint2 a = seeds[j];
-      if (a.x >= (uint32_t)ph || a.y >= (uint32_t)pw) atomicExch(err_flag, 1u);
-      if (j + 1 < n && seed_pos(seeds[j + 1], pw) < seed_pos(a, pw)) *unsorted_flag = 1u;
+// order and bounds of one wave's slice of the list.  flags: [0] seed out of bounds, [1] list not
+// sorted, [2] list not strictly increasing
+__device__ __forceinline__ void check_seed_slice(const uint2 *__restrict__ seeds, size_t n, int ph, int pw, size_t slice,
+                                                 size_t nslices, int lane, uint32_t *flags) {
+  const size_t per = (n + nslices - 1) / nslices;
+  const size_t lo = slice * per, hi = lo + per < n ? lo + per : n;
+  for (size_t j = lo + lane; j < hi; j += 64) {
+    const uint2 a = seeds[j];
+    if (a.x >= (uint32_t)ph || a.y >= (uint32_t)pw) atomicExch(&flags[0], 1u);
+    if (j + 1 < n) {
+      const unsigned long long pa = seed_pos(a, pw), pb = seed_pos(seeds[j + 1], pw);
+      if (pb < pa) flags[1] = 1u;
+      if (pb <= pa) flags[2] = 1u;
     }
   }
+}
 
-  // ---- 64-ary lower bound of the chunk start: smallest j with pos(j) >= p0
-  unsigned long long p0 = (unsigned long long)chunk * (unsigned long long)(PAINT_SEG * steps);
+// 64-ary lower bound, one probe per lane and round: smallest j with pos(j) >= p0 (4 rounds for 7 M seeds).
+// Terminates and stays inside [0, n] whatever the order of the list.
+__device__ __forceinline__ size_t seed_lower_bound(const uint2 *__restrict__ seeds, size_t n, int pw, unsigned long long p0, int lane) {
   size_t lo = 0, hi = n;
   while (hi - lo > 64) {
     const size_t step = (hi - lo + 63) / 64;
@@ -206,6 +196,28 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_
     const bool before = j < hi && seed_pos(seeds[j], pw) < p0;
     lo += __popcll(__builtin_amdgcn_ballot_w64(before));
   }
+  return lo;
+}
+
+__global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
+                                                                  uint32_t *labels, size_t npx, size_t nchunk, int steps,
+                                                                  uint32_t *err_flag,
+                                                                  uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][PAINT_SEG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
+  {   // side job: the small arrays the transform wants zeroed (tile-edge stamps, flag words)
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
+    for (size_t i = tid; i < n_zero_b; i += step) zero_b[i] = 0u;
+  }
+  const size_t chunk = (size_t)blockIdx.x * PAINT_WAVES + wave;       // `steps` consecutive segments
+  if (chunk >= nchunk) return;
+  uint32_t *row = sRow[wave];
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0;
+  check_seed_slice(seeds, n, ph, pw, chunk, nchunk, lane, err_flag);      // independent loads, issued first
+  unsigned long long p0 = (unsigned long long)chunk * (unsigned long long)(PAINT_SEG * steps);
+  const size_t lo = seed_lower_bound(seeds, n, pw, p0, lane);
 
   // ---- walk: the list from `lo` on is cut into fixed windows of 64 seeds, one per lane; `off` is the
   // first lane of the current window that has not been painted yet.  A segment paints the run of
@@ -254,26 +266,124 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_
   }
 }
 
-// Paints colour i + 1 at seed i over a zeroed plane, later duplicates winning (lib.rs:1672-1677), in
-// one pass over the plane plus a fix-up that only works when the list is not sorted.  Also zeroes two
-// small arrays.  err_flag points at two consecutive words, as for scatter_seeds; they must be zero.
-hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
-                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
-  const size_t npx = (size_t)ph * pw;
+// The side tables of a STRICTLY increasing seed list: one bit per pixel ("is a seed") and, per
+// 32-pixel word, the list index of the first seed of the word.  The colour of seed pixel p is then
+//     word_base[p / 32] + popcount(mask[p / 32] & ((1 << p % 32) - 1)) + 1,
+// 16 MiB of tables instead of a painted 256 MiB plane at 8192^2.  A wave owns TAB_WORDS words
+// (8192 pixels): lower bound of the chunk start, then every window of 64 seeds drops its bits into a
+// 1 KiB LDS row (no per-segment ordering: windows stream through four at a time), one wave scan of
+// the word popcounts gives the bases.  Nothing here repairs a list that is not strictly increasing:
+// flags[2] tells the caller, who repeats the transform with paint_labels.
+constexpr int TAB_WORDS = 256;       // mask words per wave (8192 pixels): four per lane
+
+__global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
+                                                                 uint32_t *mask, uint32_t *word_base, size_t npx, size_t nchunk,
+                                                                 uint32_t *flags,
+                                                                 uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][TAB_WORDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
+  {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
+    for (size_t i = tid; i < n_zero_b; i += step) zero_b[i] = 0u;
+  }
+  const size_t chunk = (size_t)blockIdx.x * PAINT_WAVES + wave;
+  if (chunk >= nchunk) return;
+  uint32_t *row = sRow[wave];
+  *reinterpret_cast<u32x4_z *>(&row[lane * 4]) = u32x4_z{0u, 0u, 0u, 0u};
+  check_seed_slice(seeds, n, ph, pw, chunk, nchunk, lane, flags);
+  const unsigned long long p0 = (unsigned long long)chunk * (TAB_WORDS * 32);
+  const unsigned long long p1 = p0 + TAB_WORDS * 32 < npx ? p0 + TAB_WORDS * 32 : npx;
+  const size_t lo = seed_lower_bound(seeds, n, pw, p0, lane);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the zeroed row before the bits
+
+  // four windows of 64 seeds per round, all four loads in flight together
+  for (size_t wbase = lo; wbase < n; wbase += 256) {
+    uint2 win[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t j = wbase + 64 * k + lane;
+      win[k] = seeds[j < n ? j : n - 1];
+    }
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t j = wbase + 64 * k + lane;
+      const unsigned long long pos = seed_pos(win[k], pw);
+      const bool ok = j < n && pos >= p0 && pos < p1;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+      const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);           // the leading run of seeds inside the chunk
+      if (!done && lane < run && win[k].x < (uint32_t)ph && win[k].y < (uint32_t)pw) {
+        const uint32_t b = (uint32_t)(pos - p0);
+        atomicOr(&row[b >> 5], 1u << (b & 31u));
+      }
+      done = done || run < 64;
+    }
+    if (done) break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  // lane l owns words 4l .. 4l+3 of the chunk: exclusive scan of their popcounts = seeds before them
+  const u32x4_z w = *reinterpret_cast<const u32x4_z *>(&row[lane * 4]);
+  const uint32_t c0 = __popc(w.x), c1 = __popc(w.y), c2 = __popc(w.z), cnt = c0 + c1 + c2 + __popc(w.w);
+  uint32_t incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const uint32_t b0 = (uint32_t)lo + incl - cnt;
+  const u32x4_z bases = u32x4_z{b0, b0 + c0, b0 + c0 + c1, b0 + c0 + c1 + c2};
+  const size_t wi = (size_t)(p0 >> 5) + 4 * lane, nwords = (npx + 31) / 32;
+  if (wi + 4 <= nwords && ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(word_base)) & 15u) == 0) {
+    *reinterpret_cast<u32x4_z *>(mask + wi) = w;
+    *reinterpret_cast<u32x4_z *>(word_base + wi) = bases;
+  } else {
+    const uint32_t wv[4] = {w.x, w.y, w.z, w.w}, bv[4] = {bases.x, bases.y, bases.z, bases.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (wi + k < nwords) { mask[wi + k] = wv[k]; word_base[wi + k] = bv[k]; }
+  }
+}
+
+static int paint_steps() {
   static const int steps = [] {
     const char *e = getenv("WS_PAINT_STEPS");      // tuning knob, tools/ only
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : PAINT_STEPS;
   }();
+  return steps;
+}
+
+// Paints colour i + 1 at seed i over a zeroed plane, later duplicates winning (lib.rs:1672-1677), in
+// one pass over the plane plus a fix-up that only works when the list is not sorted.  Also zeroes two
+// small arrays.  err_flag points at three consecutive words (out of bounds, unsorted, not strictly
+// increasing); they must be zero.
+hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
+                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  const size_t npx = (size_t)ph * pw;
+  const int steps = paint_steps();
   const size_t per_wave = (size_t)PAINT_SEG * steps;
   const size_t nchunk = (npx + per_wave - 1) / per_wave;
   const size_t blocks = std::max<size_t>((nchunk + PAINT_WAVES - 1) / PAINT_WAVES, 1);
-  k_paint_sorted<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, labels, npx, nchunk, steps, err_flag, err_flag + 1,
+  k_paint_sorted<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, labels, npx, nchunk, steps, err_flag,
                                                               zero_a, n_zero_a, zero_b, n_zero_b);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || n == 0) return e;
   const int fb = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
   k_scatter_fixup<<<fb, 256, 0, s>>>(seeds_rc, nullptr, n, ph, pw, labels, err_flag + 1);
+  return hipGetLastError();
+}
+
+// `mask` and `word_base` hold (ph * pw + 31) / 32 words each.  The caller reads err_flag[2] ("not strictly
+// increasing") back and, if it is raised, repeats the transform with paint_labels.
+hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
+                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  const size_t npx = (size_t)ph * pw;
+  const size_t per_wave = (size_t)TAB_WORDS * 32;
+  const size_t nchunk = (npx + per_wave - 1) / per_wave;
+  const size_t blocks = std::max<size_t>((nchunk + PAINT_WAVES - 1) / PAINT_WAVES, 1);
+  k_seed_tables<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, mask, word_base, npx, nchunk, err_flag,
+                                                             zero_a, n_zero_a, zero_b, n_zero_b);
   return hipGetLastError();
 }
 
@@ -502,9 +612,14 @@ typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 constexpr int RL_P = 72, RL_X0 = 4, RL_ROWS = TS + 2;
 constexpr uint32_t RL_FINAL = 0x8000u;          // pointer flag: the target is a root of the in-tile forest
 
-__global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
+// TABLES: the seeds were never painted; their colours come from the side tables of a strictly
+// increasing seed list (k_paint_sorted<true>) and every pixel of the plane is written here.
+template <bool TABLES>
+__global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
-                                                            uint32_t *ref_list, size_t ref_cap, uint32_t max_rounds) {
+                                                            uint32_t *ref_list, size_t ref_cap, uint32_t max_rounds,
+                                                            const uint32_t *__restrict__ seed_mask,
+                                                            const uint32_t *__restrict__ word_base) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   __shared__ uint32_t s_flag[3];
@@ -520,6 +635,8 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
 
   // ---- loads: unconditional on clamped addresses (see ws_relax.hip)
   uint32_t K[4][4], Lb[4][4];
+  uint32_t seedbits = 0;                         // TABLES: which pixels of the patch are seeds
+  uint32_t tab_mask[4] = {0u, 0u, 0u, 0u}, tab_base[4] = {0u, 0u, 0u, 0u};   // TABLES, vec: the table words of the 4 patch rows
   const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(labels)) & 15u) == 0;
   if (vec) {          // W % 4 == 0: a patch is wholly inside or wholly outside the plane in x
     const int gxc = min(gx0, W - 4);
@@ -528,7 +645,13 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     for (int r = 0; r < 4; ++r) {
       const size_t g = (size_t)min(gy0 + r, H - 1) * W + gxc;
       kv[r] = *reinterpret_cast<const u32x4_r *>(keys + g);
-      lv[r] = *reinterpret_cast<const u32x4_r *>(labels + g);
+      if (TABLES) {      // requested with the stamps (a late load would stall the whole workgroup after the rounds);
+        tab_mask[r] = seed_mask[g >> 5];      // 8 registers across the jumping rounds instead of 16 colours
+        tab_base[r] = word_base[g >> 5];
+        lv[r] = u32x4_r{0u, 0u, 0u, 0u};
+      } else {
+        lv[r] = *reinterpret_cast<const u32x4_r *>(labels + g);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -542,7 +665,7 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
       for (int c = 0; c < 4; ++c) {
         const size_t g = (size_t)min(gy0 + r, H - 1) * W + min(gx0 + c, W - 1);
         K[r][c] = keys[g];
-        Lb[r][c] = labels[g];
+        Lb[r][c] = TABLES ? 0u : labels[g];
       }
   }
   {
@@ -555,8 +678,10 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c) {
         if (!(gy0 + r < H && gx0 + c < W)) { K[r][c] = KEY_INF; Lb[r][c] = 0u; }
+        if (TABLES && K[r][c] == 0u) seedbits |= 1u << (r * 4 + c);      // only a seed (stamp 0) has a colour of its own
+      }
       *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{K[r][0], K[r][1], K[r][2], K[r][3]};
     }
     sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = hok ? hv : KEY_INF;
@@ -630,6 +755,29 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
     if (!again || it + 1 >= max_rounds) break;     // max_rounds: timing experiments only (WS_DEBUG_MAXIT)
   }
+  if (TABLES) {
+    // seed colours from the side tables; with W % 4 == 0 a patch row sits in one mask word
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gyc = min(gy0 + r, H - 1);
+      if (vec) {
+        const size_t g = (size_t)gyc * W + min(gx0, W - 4);
+        // (the asm pins the colour arithmetic here: computed early it holds 16 registers through the rounds)
+        asm volatile("" : "+v"(tab_mask[r]), "+v"(tab_base[r]));
+        const uint32_t mw = tab_mask[r], wb = tab_base[r], sh = (uint32_t)(g & 31u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          Lb[r][c] = (seedbits >> (r * 4 + c)) & 1u ? wb + __popc(mw & ((1u << (sh + c)) - 1u)) + 1u : 0u;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t g = (size_t)gyc * W + min(gx0 + c, W - 1);
+          const uint32_t col = word_base[g >> 5] + __popc(seed_mask[g >> 5] & ((1u << (g & 31u)) - 1u)) + 1u;
+          Lb[r][c] = (seedbits >> (r * 4 + c)) & 1u ? col : 0u;
+        }
+      }
+    }
+  }
   // every pointer is final and in registers: the tile now becomes the painted colours, so that the
   // colour of an in-tile root (a seed) is one LDS read
 #pragma unroll
@@ -659,7 +807,8 @@ __global__ __launch_bounds__(NTHREADS) void k_resolve_local(const uint32_t *__re
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (gx0 + c < W && (P[r][c] & (RL_FINAL - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)) labels[(size_t)gy * W + gx0 + c] = out[c];
+          if (gx0 + c < W && (TABLES || (P[r][c] & (RL_FINAL - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)))
+            labels[(size_t)gy * W + gx0 + c] = out[c];
       }
     }
   }
@@ -710,14 +859,18 @@ size_t resolve_ref_capacity(int h, int w) {
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds, bool ref_count_zeroed) {
+                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds, bool ref_count_zeroed,
+                              const uint32_t *seed_mask, const uint32_t *word_base) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t cap = resolve_ref_capacity(h, w);
   hipError_t e = ref_count_zeroed ? hipSuccess : hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
-  k_resolve_local<<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds);
+  if (seed_mask)
+    k_resolve_local<true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds, seed_mask, word_base);
+  else
+    k_resolve_local<false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds, nullptr, nullptr);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   k_resolve_chase<<<dim3(32, NSTRIPE), 256, 0, s>>>(labels, ref_count, ref_list, cap, n);

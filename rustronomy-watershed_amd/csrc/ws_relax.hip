@@ -73,6 +73,11 @@ __device__ __forceinline__ void relax_px(uint32_t &t, uint32_t b, uint32_t u, ui
   t = n;
 }
 
+// element p of a u32 plane, or bit p of a bit plane
+__device__ __forceinline__ uint32_t plane_or_bit(const uint32_t *src, size_t p, int bits) {
+  return bits ? (src[p >> 5] >> (p & 31u)) & 1u : src[p];
+}
+
 typedef uint32_t patch_t[RX_P][RX_P];
 
 // A sweep updates a whole patch row (or column) at a time: its 4 pixels are independent (they use
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
-                                                      const uint32_t *__restrict__ seed_labels) {
+                                                      const uint32_t *__restrict__ seed_labels, int seed_bits) {
   constexpr int TH = NW * RX_P;
   // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
   __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NW + 2][RX_TW];
@@ -221,9 +226,27 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   // pass 0 of a whole-image transform reads the freshly painted LABEL plane instead of a stamp
   // plane (seed = coloured pixel = stamp 0, everything else never-coloured): nobody has to fill the
   // stamp plane first, this pass writes all of it
+  // (seed_bits: the "plane" is one bit per pixel instead -- the side table of a strictly increasing
+  // seed list, ws_kernels.hip; only offered for W % 4 == 0, so a patch row is one nibble of one word)
   const bool from_labels = seed_labels != nullptr;
   const uint32_t *ksrc = from_labels ? seed_labels : keys;
-  if (fast) {
+  if (fast && seed_bits) {
+    uint32_t iv[RX_P];
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const int gyc = min(max(gyb + r, 0), H - 1);
+      const size_t p = (size_t)gyc * W + gxc0, ph_ = (size_t)gyc * W + xh;
+      const uint32_t nib = ksrc[p >> 5] >> (p & 31u);
+      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
+      halo[r] = (ksrc[ph_ >> 5] >> (ph_ & 31u)) & 1u;
+      T[r][0] = nib & 1u; T[r][1] = nib & 2u; T[r][2] = nib & 4u; T[r][3] = nib & 8u;
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) B[r][c] = (iv[r] >> (8 * c)) & 0xFFu;
+    }
+    const size_t p = (size_t)gy_halo * W + gxc0;
+    const uint32_t nib = ksrc[p >> 5] >> (p & 31u);
+    halo_row = u32x4_t{nib & 1u, nib & 2u, nib & 4u, nib & 8u};
+  } else if (fast) {
     u32x4_t kv[RX_P];
     uint32_t iv[RX_P];
 #pragma unroll
@@ -247,15 +270,15 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
 #pragma unroll
       for (int c = 0; c < RX_P; ++c) {
         const int gxc = min(max(gx0 + c, 0), W - 1);
-        T[r][c] = ksrc[(size_t)gyc * W + gxc];
+        T[r][c] = plane_or_bit(ksrc, (size_t)gyc * W + gxc, seed_bits);
         B[r][c] = img[(size_t)gyc * img_stride + gxc];
       }
-      halo[r] = ksrc[(size_t)gyc * W + xh];
+      halo[r] = plane_or_bit(ksrc, (size_t)gyc * W + xh, seed_bits);
     }
-    halo_row.x = ksrc[(size_t)gy_halo * W + min(max(gx0 + 0, 0), W - 1)];
-    halo_row.y = ksrc[(size_t)gy_halo * W + min(max(gx0 + 1, 0), W - 1)];
-    halo_row.z = ksrc[(size_t)gy_halo * W + min(max(gx0 + 2, 0), W - 1)];
-    halo_row.w = ksrc[(size_t)gy_halo * W + min(max(gx0 + 3, 0), W - 1)];
+    halo_row.x = plane_or_bit(ksrc, (size_t)gy_halo * W + min(max(gx0 + 0, 0), W - 1), seed_bits);
+    halo_row.y = plane_or_bit(ksrc, (size_t)gy_halo * W + min(max(gx0 + 1, 0), W - 1), seed_bits);
+    halo_row.z = plane_or_bit(ksrc, (size_t)gy_halo * W + min(max(gx0 + 2, 0), W - 1), seed_bits);
+    halo_row.w = plane_or_bit(ksrc, (size_t)gy_halo * W + min(max(gx0 + 3, 0), W - 1), seed_bits);
   }
   if (from_labels) {
 #pragma unroll
@@ -447,7 +470,7 @@ size_t relax_tiles(int h, int w) {
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels) {
+                      const uint32_t *seed_labels, bool seed_bits) {
   const int th = RX_NW * RX_P;
   const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + th - 1) / th;     // grid anchored at (0, 0): even passes
   const int sx = ax + 1, sy = ay + 1;                                 // grid shifted by half a tile: odd passes
@@ -464,11 +487,12 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }();
   if (pass < chunk_from) {
     k_relax<RX_NW, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                         prev, cur, pf, max_iters, pass == 0 ? seed_labels : nullptr);
+                                                         prev, cur, pf, max_iters, pass == 0 ? seed_labels : nullptr,
+                                                         pass == 0 && seed_labels && seed_bits ? 1 : 0);
   } else {
     const int chunk = 4;
     k_relax<RX_NW, true><<<(tx * ty + chunk - 1) / chunk, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted,
-                                                                              chunk, max_level, pass, prev, cur, pf, max_iters, nullptr);
+                                                                              chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0);
   }
   return hipGetLastError();
 }
