@@ -294,9 +294,8 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   // no host round trip here: the error words are read once, after the resolve launches are queued
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
-    if ((rc = ensure(c, c->refs, NSTRIPE * resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, flags + FLAG_REFS, (uint32_t *)c->refs.p, c->debug_max_iters, true,
-                                  seed_mask, word_base));
+    if ((rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base));
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {

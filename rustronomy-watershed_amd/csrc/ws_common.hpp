@@ -67,11 +67,10 @@ size_t resolve_tiles(int h, int w);
 hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
                         uint32_t pass, uint32_t *stamps, PassFlags pf);
 // label resolve without a launch loop (pointer jumping in LDS + reference chase); needs h*w < 2^31
-// ref_count: FLAG_SLOT words of striped counters; ref_list: NSTRIPE * resolve_ref_capacity(h, w) words
+// ref_scratch: resolve_ref_capacity(h, w) words (per-wave work lists of the pixels whose chain leaves their tile)
 size_t resolve_ref_capacity(int h, int w);
-hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds = 0xFFFFFFFFu,
-                              bool ref_count_zeroed = false,
+hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
+                              uint32_t max_rounds = 0xFFFFFFFFu,
                               const uint32_t *seed_mask = nullptr, const uint32_t *word_base = nullptr);   // seed_tables() form
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,

@@ -8,6 +8,12 @@
 #include <algorithm>
 #include <cstdlib>
 
+// per-workgroup phase stamps: only in the diagnostic builds under tools/ (they define the macro)
+#ifndef WS_STAMP
+#define WS_STAMP(slot) do {} while (0)
+#define WS_STAMP_VALUE(slot, v) do {} while (0)
+#endif
+
 namespace wsk {
 
 // ---------------------------------------------------------------- small utilities ----
@@ -602,6 +608,7 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 // Needs pixel indices < 2^31 (planes up to 46340^2); larger planes use the k_resolve loop.
 
 constexpr uint32_t REF_BIT = 0x80000000u;
+constexpr size_t REF_REGION = 64 * 16;          // work-list entries per wave of k_resolve_local: its pixels
 
 typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 
@@ -611,19 +618,19 @@ typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 // ring sits at rows 0 / 65 and columns 3 / 68.
 constexpr int RL_P = 72, RL_X0 = 4, RL_ROWS = TS + 2;
 constexpr uint32_t RL_FINAL = 0x8000u;          // pointer flag: the target is a root of the in-tile forest
+constexpr uint32_t RL_HALO = 0x4000u;           // pointer flag: ... namely a halo cell, where the chain leaves the tile
+static_assert(RL_ROWS * RL_P <= (int)RL_HALO, "cell indices must stay below the flag bits");
 
 // TABLES: the seeds were never painted; their colours come from the side tables of a strictly
 // increasing seed list (k_paint_sorted<true>) and every pixel of the plane is written here.
 template <bool TABLES>
-__global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
+__global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
-                                                            uint32_t *ref_list, size_t ref_cap, uint32_t max_rounds,
+                                                            uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
                                                             const uint32_t *__restrict__ word_base) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
-  __shared__ uint32_t s_flag[3];
-  __shared__ uint32_t s_wave_refs[NTHREADS / 64], s_ref_base;
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
   const int x0 = tile_x * TS, y0 = tile_y * TS;
   const int gx0 = x0 + pc * 4, gy0 = y0 + pr * 4;
   const int lx0 = RL_X0 + pc * 4, ly0 = 1 + pr * 4;
-  if (tid < 3) s_flag[tid] = 0;
+  WS_STAMP(0);
 
   // ---- loads: unconditional on clamped addresses (see ws_relax.hip)
   uint32_t K[4][4], Lb[4][4];
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
     sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = hok ? hv : KEY_INF;
   }
   __syncthreads();
+  WS_STAMP(1);
 
   // ---- parent pointer of every pixel of the patch.  A pointer carries RL_FINAL when its target is a
   // root of the in-tile forest (a seed, or a halo cell = where the chain leaves the tile): such a
@@ -700,32 +708,42 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
     uint32_t Lc[4], Rc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Lc[r] = sB[(ly0 + r) * RL_P + lx0 - 1]; Rc[r] = sB[(ly0 + r) * RL_P + lx0 + 4]; }
-    const bool top_halo = pr == 0, bot_halo = pr == 15, left_halo = pc == 0, right_halo = pc == 15;
+    // Branch-free on purpose, 0/1 words and selects only: written with `if` / `&&` this block compiled
+    // to ~75 instructions per pixel of exec-mask juggling and was the longest phase of the kernel.
+    const uint32_t top_halo = pr == 0, bot_halo = pr == 15, left_halo = pc == 0, right_halo = pc == 15;
+    uint32_t row_int[4], col_int[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      row_int[i] = (uint32_t)(gy0 + i >= 1) & (uint32_t)(gy0 + i < H - 1);
+      col_int[i] = (uint32_t)(gx0 + i >= 1) & (uint32_t)(gx0 + i < W - 1);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int gy = gy0 + r;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int gx = gx0 + c;
         const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
         const uint32_t k = K[r][c];
-        uint32_t p = cell | RL_FINAL;
-        // flooded pixels are interior pixels (lib.rs:220-222); first earlier neighbour in D,R,L,U
-        // (lib.rs:190, 245); "up" is the fall-through: at a fixpoint one of the four is earlier
-        if (k != 0u && k != KEY_INF && gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
-          const uint32_t d = r == 3 ? dn[c] : K[r + 1][c];
-          const uint32_t rr = c == 3 ? Rc[r] : K[r][c + 1];
-          const uint32_t l = c == 0 ? Lc[r] : K[r][c - 1];
-          const uint32_t u = r == 0 ? up[c] : K[r - 1][c];
-          const bool td = d < k, tr = rr < k, tl = l < k;
-          const uint32_t tgt = td ? cell + RL_P : (tr ? cell + 1 : (tl ? cell - 1 : cell - RL_P));
-          const uint32_t kp = td ? d : (tr ? rr : (tl ? l : u));
-          const bool halo = td ? (r == 3 && bot_halo) : (tr ? (c == 3 && right_halo) : (tl ? (c == 0 && left_halo) : (r == 0 && top_halo)));
-          const bool fin = kp == 0u || halo;
-          p = tgt | (fin ? RL_FINAL : 0u);
-          if (!fin) live |= 1u << (r * 4 + c);
-        }
-        P[r][c] = p;
+        // flooded pixels are interior pixels (lib.rs:220-222) with a finite, non-seed stamp
+        const uint32_t flood = (uint32_t)(k - 1u < KEY_INF - 1u) & row_int[r] & col_int[c];
+        const uint32_t d = r == 3 ? dn[c] : K[r + 1][c];
+        const uint32_t rr = c == 3 ? Rc[r] : K[r][c + 1];
+        const uint32_t l = c == 0 ? Lc[r] : K[r][c - 1];
+        const uint32_t u = r == 0 ? up[c] : K[r - 1][c];
+        // first earlier neighbour in D,R,L,U (lib.rs:190, 245); "up" is the fall-through: at a
+        // fixpoint one of the four is earlier
+        const uint32_t td = d < k, tr = rr < k, tl = l < k;
+        const uint32_t tgt = cell + (uint32_t)(td ? RL_P : (tr ? 1 : (tl ? -1 : -RL_P)));
+        const uint32_t kp = td ? d : (tr ? rr : (tl ? l : u));
+        // does the chosen step leave the tile?  (r, c are compile-time: most terms vanish)
+        uint32_t out_of_tile = 0;
+        if (r == 3) out_of_tile |= td & bot_halo;
+        if (c == 3) out_of_tile |= (td ^ 1u) & tr & right_halo;
+        if (c == 0) out_of_tile |= (td ^ 1u) & (tr ^ 1u) & tl & left_halo;
+        if (r == 0) out_of_tile |= (td ^ 1u) & (tr ^ 1u) & (tl ^ 1u) & top_halo;
+        const uint32_t fin = (uint32_t)(kp == 0u) | out_of_tile;
+        const uint32_t moving = tgt | (fin ? RL_FINAL : 0u) | (out_of_tile ? RL_HALO : 0u);
+        P[r][c] = flood ? moving : (cell | RL_FINAL);
+        live |= (flood & (fin ^ 1u)) << (r * 4 + c);
       }
     }
   }
@@ -734,8 +752,16 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
   for (int r = 0; r < 4; ++r)
     *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{P[r][0], P[r][1], P[r][2], P[r][3]};
   __syncthreads();
+  WS_STAMP(2);
 
-  for (uint32_t it = 0;; ++it) {                 // pointer jumping: P <- P(P), until P's target is a root
+  // Pointer jumping, P <- P(P), until P's target is a root -- WITHOUT rounds: every value a pixel can
+  // read from the tile, old or freshly compressed by its owner, is a pointer to one of its ancestors
+  // (flagged when that ancestor is a root), so threads neither wait for each other nor agree on
+  // when to stop; a thread is done when its own 16 pointers are final.  One barrier after the loop
+  // (the tile is reused for colours), none inside.
+  for (uint32_t it = 0; live != 0 && it < max_rounds; ++it) {       // max_rounds: timing experiments only (WS_DEBUG_MAXIT)
+    // (tried: all 16 reads issued up front on clamped cells, no per-pixel branch -- the extra LDS traffic
+    // of the pixels that are done cost more than the serialised waits)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -747,14 +773,10 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
           if (g & RL_FINAL) live &= ~(1u << (r * 4 + c));
         }
       }
-    // one barrier per round: flag slot it % 3 (see k_relax)
-    const uint32_t slot = it % 3;
-    if (__builtin_amdgcn_ballot_w64(live != 0) != 0 && lane == 0) s_flag[slot] = 1;
-    __syncthreads();
-    const bool again = s_flag[slot] != 0;
-    if (tid == 0) s_flag[(slot + 2) % 3] = 0;
-    if (!again || it + 1 >= max_rounds) break;     // max_rounds: timing experiments only (WS_DEBUG_MAXIT)
+    WS_STAMP_VALUE(6, it + 1);
   }
+  __syncthreads();
+  WS_STAMP(3);
   if (TABLES) {
     // seed colours from the side tables; with W % 4 == 0 a patch row sits in one mask word
 #pragma unroll
@@ -786,6 +808,7 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
   __syncthreads();
 
   uint32_t refmask = 0;                          // pixels whose chain leaves the tile
+  const uint32_t g_origin = (uint32_t)((size_t)(y0 - 1) * W + x0 - RL_X0);      // global index of LDS cell (0, 0); n < 2^31, wraps harmlessly
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gy = gy0 + r;
@@ -793,13 +816,13 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
-      const uint32_t t = P[r][c] & (RL_FINAL - 1u);
-      const int rly = (int)(t / RL_P), rlx = (int)(t - (uint32_t)rly * RL_P);
-      const bool inside = rly >= 1 && rly <= TS && rlx >= RL_X0 && rlx < RL_X0 + TS;
-      const size_t rg = (size_t)(y0 - 1 + rly) * W + (size_t)(x0 - RL_X0 + rlx);
-      const uint32_t col = sB[inside ? t : cell];
-      out[c] = t == cell ? Lb[r][c] : (inside ? col : (REF_BIT | (uint32_t)rg));
-      if (t != cell && !inside && gy < H && gx0 + c < W) refmask |= 1u << (r * 4 + c);
+      const uint32_t pv = P[r][c];
+      const uint32_t t = pv & (RL_HALO - 1u);
+      const bool leaves = (pv & RL_HALO) != 0u;
+      const uint32_t rly = t / RL_P, rlx = t - rly * RL_P;
+      const uint32_t rg = g_origin + rly * (uint32_t)W + rlx;
+      out[c] = t == cell ? Lb[r][c] : (leaves ? (REF_BIT | rg) : sB[t]);      // the root's colour is one LDS read
+      if (leaves && gy < H && gx0 + c < W) refmask |= 1u << (r * 4 + c);
     }
     if (gy < H) {
       if (vec) {
@@ -807,73 +830,73 @@ __global__ __launch_bounds__(NTHREADS, 6) void k_resolve_local(const uint32_t *_
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (gx0 + c < W && (TABLES || (P[r][c] & (RL_FINAL - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)))
+          if (gx0 + c < W && (TABLES || (P[r][c] & (RL_HALO - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)))
             labels[(size_t)gy * W + gx0 + c] = out[c];
       }
     }
   }
-  // work list of the reference pixels for k_resolve_chase: one striped reservation per workgroup
-  // (workgroups of one stripe share a counter: ntiles / NSTRIPE adds per address, not ntiles)
+  WS_STAMP(4);
+  // work list of the reference pixels for k_resolve_chase: every WAVE owns a fixed region of the list
+  // (64 lanes x 16 pixels) and a count word -- no reservation atomic, no barrier, no cross-wave offsets
+  // (a returning atomicAdd per workgroup kept all four waves waiting ~1.5 us)
   const uint32_t cnt = __popc(refmask);
   uint32_t incl = cnt;
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t v = __shfl_up(incl, off, 64);
     if (lane >= off) incl += v;
   }
-  if (lane == 63) s_wave_refs[wave] = incl;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t total = 0;
-    for (int k = 0; k < NTHREADS / 64; ++k) total += s_wave_refs[k];
-    s_ref_base = total ? atomicAdd(&ref_count[(blockIdx.x % NSTRIPE) * STRIPE_STRIDE], total) : 0u;
-  }
-  __syncthreads();
+  const size_t region = (size_t)blockIdx.x * (NTHREADS / 64) + wave;
+  if (lane == 63) ref_count[region] = incl;
   if (refmask) {
-    uint32_t pos = s_ref_base + incl - cnt;
-    for (int k = 0; k < wave; ++k) pos += s_wave_refs[k];
-    uint32_t *dst = ref_list + (size_t)(blockIdx.x % NSTRIPE) * ref_cap;
+    uint32_t *dst = ref_list + region * REF_REGION + (incl - cnt);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if ((refmask >> i) & 1u) dst[pos++] = (uint32_t)((size_t)(gy0 + (i >> 2)) * W + gx0 + (i & 3));
+      if ((refmask >> i) & 1u) *dst++ = (uint32_t)((size_t)(gy0 + (i >> 2)) * W + gx0 + (i & 3));
   }
+  WS_STAMP(5);
 }
 
-// blockIdx.y = stripe of the work list; a reference always points to a pixel with a strictly smaller
-// stamp, so chains end at a seed; a racing reader sees either the reference or what it resolves to
+// One wave per list region (grid-stride).  A reference always points to a pixel with a strictly
+// smaller stamp, so chains end at a seed; a racing reader sees either the reference or what it
+// resolves to.
 __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
-                                const uint32_t *__restrict__ ref_list, size_t ref_cap, size_t n) {
-  const uint32_t count = ref_count[blockIdx.y * STRIPE_STRIDE];
-  const uint32_t *list = ref_list + (size_t)blockIdx.y * ref_cap;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
-    const uint32_t i = list[j];
-    uint32_t v = labels[i];
-    for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
-      v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    labels[i] = v;
+                                const uint32_t *__restrict__ ref_list, size_t nregions, size_t n) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t region = wave0; region < nregions; region += nwaves) {
+    const uint32_t count = ref_count[region];
+    const uint32_t *list = ref_list + region * REF_REGION;
+    for (uint32_t j = lane; j < count; j += 64) {
+      const uint32_t i = list[j];
+      uint32_t v = labels[i];
+      for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
+        v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      labels[i] = v;
+    }
   }
 }
 
+// words of scratch the two-launch resolve needs: a count and a REF_REGION-entry list per wave of k_resolve_local
 size_t resolve_ref_capacity(int h, int w) {
-  const size_t ntiles = (size_t)tiles_of(w) * tiles_of(h);
-  return ((ntiles + NSTRIPE - 1) / NSTRIPE) * (size_t)(TS * TS);    // per stripe: its workgroups x pixels per tile
+  const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
+  return nregions * (1 + REF_REGION);
 }
 
-hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w,
-                              uint32_t *ref_count, uint32_t *ref_list, uint32_t max_rounds, bool ref_count_zeroed,
-                              const uint32_t *seed_mask, const uint32_t *word_base) {
+hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
+                              uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
-  const size_t cap = resolve_ref_capacity(h, w);
-  hipError_t e = ref_count_zeroed ? hipSuccess : hipMemsetAsync(ref_count, 0, FLAG_SLOT * sizeof(uint32_t), s);
-  if (e != hipSuccess) return e;
+  const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
+  uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
   if (seed_mask)
-    k_resolve_local<true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds, seed_mask, word_base);
+    k_resolve_local<true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base);
   else
-    k_resolve_local<false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, cap, max_rounds, nullptr, nullptr);
-  e = hipGetLastError();
+    k_resolve_local<false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  k_resolve_chase<<<dim3(32, NSTRIPE), 256, 0, s>>>(labels, ref_count, ref_list, cap, n);
+  const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n);
   return hipGetLastError();
 }
 

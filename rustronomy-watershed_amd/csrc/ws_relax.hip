@@ -46,8 +46,13 @@ __device__ unsigned long long *g_diag = nullptr;
   do {                                                                                          \
     if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#define WS_STAMP_VALUE(slot, v)                                                                 \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = (v);              \
+  } while (0)
 #else
 #define WS_STAMP(slot) do {} while (0)
+#define WS_STAMP_VALUE(slot, v) do {} while (0)
 #endif
 
 constexpr int RX_TW = 256;   // tile width: 64 lanes x 4 columns
