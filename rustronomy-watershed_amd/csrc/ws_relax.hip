@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     s_sum[tid] = sum_before;
   }
   uint32_t iters = 0;
+  bool unfinished = max_iters == 0;      // left before the checked sweep came back clean (round cap)
   for (; max_iters != 0;) {
     ++iters;
     bool changed = false, untracked = false;
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     __syncthreads();
     const bool again = s_flag[slot] != 0;
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
-    if (!again || iters >= max_iters) break;
+    if (!again) break;
+    if (iters >= max_iters) { unfinished = true; break; }
   }
   uint64_t sum_after = 0;
 #pragma unroll
@@ -420,6 +422,9 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
         ovf |= (T[r][c] != 0u && T[r][c] < KEY_INF && (T[r][c] & RING_MASK) == 0u);
     }
     e |= 16u;
+    // A tile that stopped at the round cap is not a fixpoint of its own pixels: the four tiles of the
+    // other grid that cover it re-examine all of it in the next pass.
+    if (unfinished) e |= 15u;
     // bit q: a BORDER pixel of the tile inside quadrant q = 2*(lower half) + (right half) changed
     const uint32_t qbit = 1u << ((band >= NW / 2 ? 2 : 0) + (lane >= 32 ? 1 : 0));
     if (band == 0) {
@@ -485,6 +490,14 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *prev = stamps + ((pass + 1) & 1) * cap;
   uint32_t *cur = stamps + (pass & 1) * cap;
   const int ox_ = shifted ? ax : sx, oy_ = shifted ? ay : sy;        // the previous pass's grid
+  // Pass 0 only has to produce a good first guess: pass 1 re-examines every pixel on the shifted grid
+  // anyway (a capped tile raises all four of its quadrant flags), so its last round -- the one that
+  // finds nothing left to do, a third of its time on the bench field -- is not worth running.
+  static const uint32_t p0_rounds = [] {
+    const char *e = getenv("WS_RELAX_P0_ROUNDS");        // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : 2u;
+  }();
+  if (pass == 0 && p0_rounds < max_iters) max_iters = p0_rounds;
   // passes 0 and 1 run every tile and pass 2 about half of them (bench field): one tile per workgroup
   static const uint32_t chunk_from = [] {
     const char *e = getenv("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
