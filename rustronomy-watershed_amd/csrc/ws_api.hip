@@ -1022,8 +1022,10 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
   {
     Span sp(c, KC_OTHER);
-    HIP_TRY(c, union_image(c->stream, (const uint32_t *)c->keys.p, seg, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p));
-    HIP_TRY(c, relabel_u32(c->stream, (const uint32_t *)c->keys.p, seg, (uint32_t *)c->uf_parent.p, d_labels, n, opt->max_water_level));
+    // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
+    if ((rc = ensure(c, c->counts, std::max<size_t>(union_image_tiles((int)ph, (int)pw), 1) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(c, union_image(c->stream, seg, d_seeds_rc, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p));
+    HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n));
   }
   c->stats.merge_levels = 1;
   return stats_end(c);

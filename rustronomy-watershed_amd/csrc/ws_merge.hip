@@ -8,6 +8,8 @@
 #include "ws_common.hpp"
 #include "ws_merge.hpp"
 
+#include <algorithm>
+
 namespace wsk {
 
 // Reads of the forest may be stale: parents only ever decrease along a chain, so an old value is
@@ -297,8 +299,9 @@ __device__ __forceinline__ void lds_union(uint32_t *P, uint32_t a, uint32_t b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_union_tiles(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
-                                                     int H, int W, int tilesX, uint32_t *parent) {
+__global__ __launch_bounds__(256) void k_union_tiles(const uint32_t *__restrict__ labels, int H, int W, int tilesX, uint32_t *parent,
+                                                     const uint32_t *__restrict__ tile_min) {
+  if (tile_min[blockIdx.x] != 0u) return;          // a one-lake tile: k_tile_scan and k_union_seeds deal with it
   __shared__ uint32_t sP[UT * UT];        // local forest over the tile's pixels
   __shared__ uint32_t sMin[UT * UT];      // smallest colour of a local component, kept at its root
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
@@ -313,17 +316,18 @@ __global__ __launch_bounds__(256) void k_union_tiles(const uint32_t *__restrict_
   for (int i = 0; i < UT_PX; ++i) {
     const int gy = gy0 + i, gyc = min(gy, H - 1);
     const size_t g = (size_t)gyc * W + gxc;
-    const uint32_t k = keys[g], l = labels[g];
-    const uint32_t kr = keys[(size_t)gyc * W + min(gx + 1, W - 1)], lr = labels[(size_t)gyc * W + min(gx + 1, W - 1)];
-    col[i] = (gy < H && gx < W && k != KEY_INF) ? l : 0u;
-    colR[i] = (gy < H && gx + 1 < W && kr != KEY_INF) ? lr : 0u;
+    // final level: a pixel is coloured exactly when its label is non-zero (the stamps are not read)
+    const uint32_t l = labels[g];
+    const uint32_t lr = labels[(size_t)gyc * W + min(gx + 1, W - 1)];
+    col[i] = (gy < H && gx < W) ? l : 0u;
+    colR[i] = (gy < H && gx + 1 < W) ? lr : 0u;
     sP[(strip * UT_PX + i) * UT + lane] = (uint32_t)((strip * UT_PX + i) * UT + lane);
     sMin[(strip * UT_PX + i) * UT + lane] = 0xFFFFFFFFu;
   }
   {
     const int gy = gy0 + UT_PX, gyc = min(gy, H - 1);
-    const uint32_t k = keys[(size_t)gyc * W + gxc], l = labels[(size_t)gyc * W + gxc];
-    colD_last = (gy < H && gx < W && k != KEY_INF) ? l : 0u;
+    const uint32_t l = labels[(size_t)gyc * W + gxc];
+    colD_last = (gy < H && gx < W) ? l : 0u;
   }
   __syncthreads();
 
@@ -374,11 +378,189 @@ __global__ __launch_bounds__(256) void k_union_tiles(const uint32_t *__restrict_
   }
 }
 
-hipError_t union_image(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
-                       uint32_t *parent) {
+typedef uint32_t u32x4_m __attribute__((ext_vector_type(4)));
+
+// the four corner pixels of the image touch border pixels only: a seed there never joins anything
+__device__ __forceinline__ bool image_corner(int y, int x, int H, int W) { return (y == 0 || y == H - 1) && (x == 0 || x == W - 1); }
+
+// ---- one-lake tiles -------------------------------------------------------------------------
+//
+// At the final level of an ordinary field nearly every 64 x 64 tile is a single lake: every pixel of it
+// that is an interior pixel of the image is coloured.  (Those pixels form a rectangle, so they are
+// 4-connected; a coloured pixel of the image border joins through its inward neighbour, which the
+// adjacency rule of find_merge allows: one endpoint interior, lib.rs:411-434.)  For such a tile nothing
+// has to be discovered locally, and two such tiles that share an edge are always joined across it.
+// What remains is bookkeeping, split so that no thread idles behind another's union latency and no
+// crowd of unions walks the same chain at once:
+//   k_tile_scan    per tile: "one lake?" and its smallest colour cmin -> tile_min (0 = no)
+//   k_tile_links   per tile: joins cmin with the cmin of the one-lake tile to the right / below;
+//                  k_tile_roots then replaces every tile's cmin by the root of its lake
+//   k_union_seeds  per SEED: colour i+1 joins the cmin of the tile its seed pixel lies in
+//   k_tile_edges   per tile edge pixel: the colours a tile can hold WITHOUT their seed came in over an
+//                  edge; one whose seed sits in another one-lake tile is joined already (by the two
+//                  lines above), the others join cmin here, as do the colours across the right /
+//                  bottom edge when the tile there is not a one-lake tile
+//   k_union_tiles  the general path (LDS union-find) for the tiles k_tile_scan turned down
+__global__ __launch_bounds__(256) void k_tile_scan(const uint32_t *__restrict__ labels, int H, int W, int tilesX, uint32_t *tile_min) {
+  __shared__ uint32_t sWaveMin[4];
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = tile_x * UT, y0 = tile_y * UT;
+  // 16 pixels per thread: patch (tid & 15, tid >> 4); one 16-byte load per row when the rows are aligned and
+  // the patch lies inside the plane
+  const int gx0 = x0 + (tid & 15) * 4, gy0 = y0 + (tid >> 4) * 4;
+  const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(labels) & 15u) == 0 && gx0 + 4 <= W;
+  uint32_t tmin1 = 0xFFFFFFFFu;      // smallest (colour - 1): an uncoloured pixel (0) wraps to the top and never wins
+  bool ok = true;                    // every in-plane image-interior pixel seen is coloured
+  bool any_interior = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gy = gy0 + r, gyc = min(gy, H - 1);
+    uint32_t v[4];
+    if (vec) {
+      const u32x4_m q = *reinterpret_cast<const u32x4_m *>(labels + (size_t)gyc * W + gx0);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = labels[(size_t)gyc * W + min(gx0 + c, W - 1)];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gx = gx0 + c;
+      const bool in_plane = gy < H && gx < W;
+      const bool inter = in_plane && interior(gy, gx, H, W);
+      if (in_plane && !image_corner(gy, gx, H, W)) tmin1 = min(tmin1, v[c] - 1u);
+      ok = ok && (!inter || v[c] != 0u);
+      any_interior = any_interior || inter;
+    }
+  }
+  const bool one_lake = __syncthreads_and(ok) != 0 && __syncthreads_or(any_interior) != 0;
+  for (int o = 32; o > 0; o >>= 1) tmin1 = min(tmin1, (uint32_t)__shfl_xor(tmin1, o, 64));
+  if (lane == 0) sWaveMin[wave] = tmin1;
+  __syncthreads();
+  if (tid == 0) tile_min[blockIdx.x] = one_lake ? min(min(sWaveMin[0], sWaveMin[1]), min(sWaveMin[2], sWaveMin[3])) + 1u : 0u;
+}
+
+__global__ void k_tile_links(const uint32_t *__restrict__ tile_min, int tilesX, int tilesY, uint32_t *parent) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tilesX * tilesY) return;
+  const uint32_t m = tile_min[t];
+  if (m == 0u) return;
+  const int tx = t % tilesX, ty = t / tilesX;
+  const uint32_t mr = tx + 1 < tilesX ? tile_min[t + 1] : 0u, md = ty + 1 < tilesY ? tile_min[t + tilesX] : 0u;
+  if (mr != 0u && mr != m) uf_union(parent, m, mr);
+  if (md != 0u && md != m) uf_union(parent, m, md);
+}
+
+// after the links: every one-lake tile remembers the ROOT of its lake instead of its own smallest colour, so
+// that the 450 seeds of a tile find a root in one load instead of all walking (and compressing) the same chain
+__global__ void k_tile_roots(uint32_t *tile_min, int ntiles, uint32_t *parent) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const uint32_t m = tile_min[t];
+  if (m != 0u) tile_min[t] = uf_find(parent, m);
+}
+
+__global__ void k_union_seeds(const uint32_t *__restrict__ seeds_rc, size_t n_seeds, int H, int W, int tilesX,
+                              const uint32_t *__restrict__ tile_min, uint32_t *parent) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n_seeds; i += step) {
+    const uint2 rc = reinterpret_cast<const uint2 *>(seeds_rc)[i];
+    const uint32_t cmin = tile_min[(size_t)(rc.x / UT) * tilesX + rc.y / UT];
+    if (cmin != 0u && cmin != (uint32_t)(i + 1) && !image_corner((int)rc.x, (int)rc.y, H, W)) uf_union(parent, (uint32_t)(i + 1), cmin);
+  }
+}
+
+// wave = edge of the tile (0 bottom, 1 right, 2 top, 3 left), lane = position along it
+__global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ seeds_rc,
+                                                    int H, int W, int tilesX, int tilesY,
+                                                    const uint32_t *__restrict__ tile_min, uint32_t *parent) {
+  const uint32_t cmin = tile_min[blockIdx.x];
+  if (cmin == 0u) return;
+  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = tile_x * UT, y0 = tile_y * UT;
+  const int ylast = min(y0 + UT, H) - 1, xlast = min(x0 + UT, W) - 1;       // the tile's last row / column inside the plane
+  const int ey = wave == 0 ? ylast : (wave == 2 ? y0 : y0 + lane);
+  const int ex = wave == 1 ? xlast : (wave == 3 ? x0 : x0 + lane);
+  const bool own_ok = ey <= ylast && ex <= xlast;
+  const int fy = ey + (wave == 0 ? 1 : 0), fx = ex + (wave == 1 ? 1 : 0);
+  const bool far_ok = own_ok && wave < 2 && fy < H && fx < W;
+  // unconditional loads on clamped addresses (ws_relax.hip)
+  const uint32_t own_v = labels[(size_t)min(ey, H - 1) * W + min(ex, W - 1)];
+  const uint32_t far_v = labels[(size_t)min(fy, H - 1) * W + min(fx, W - 1)];
+  const uint32_t own = own_ok && !image_corner(ey, ex, H, W) ? own_v : 0u, far = far_ok ? far_v : 0u;
+  // the tile the seed of `own` lies in (colour c belongs to seed c - 1)
+  const uint2 src = reinterpret_cast<const uint2 *>(seeds_rc)[own ? own - 1u : 0u];
+  const uint32_t seed_tile_min = tile_min[(size_t)(src.x / UT) * tilesX + src.y / UT];
+  // one union per run of equal colours that want one
+  const uint32_t want_own = (own != 0u && own != cmin && seed_tile_min == 0u) ? own : 0u;
+  const uint32_t want_own_prev = __shfl_up(want_own, 1, 64);
+  if (want_own != 0u && (lane == 0 || want_own != want_own_prev)) uf_union(parent, want_own, cmin);
+  // across the right / bottom edge: only when the tile there is not a one-lake tile (else k_tile_links joined the two)
+  const int nb = wave == 0 ? (tile_y + 1 < tilesY ? (int)blockIdx.x + tilesX : -1) : (tile_x + 1 < tilesX ? (int)blockIdx.x + 1 : -1);
+  const uint32_t nb_min = (wave < 2 && nb >= 0) ? tile_min[nb] : 1u;
+  const bool pair_ok = own != 0u && far != 0u && (interior(ey, ex, H, W) || interior(fy, fx, H, W));
+  const uint32_t want_far = (pair_ok && nb_min == 0u && far != cmin) ? far : 0u;
+  const uint32_t want_far_prev = __shfl_up(want_far, 1, 64);
+  if (want_far != 0u && (lane == 0 || want_far != want_far_prev)) uf_union(parent, want_far, cmin);
+}
+
+// tile_min: union_image_tiles(h, w) words of scratch
+hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *seeds_rc, size_t n_seeds, int h, int w,
+                       uint32_t *parent, uint32_t *tile_min) {
   if (h == 0 || w == 0) return hipSuccess;
   const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
-  k_union_tiles<<<tx * ty, 256, 0, s>>>(keys, labels, h, w, tx, parent);
+  hipError_t e;
+  k_tile_scan<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, tile_min);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  k_tile_links<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx, ty, parent);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (n_seeds) {
+    const int blocks = (int)std::min<size_t>((n_seeds + 255) / 256, 16384);
+    k_union_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n_seeds, h, w, tx, tile_min, parent);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    k_tile_edges<<<tx * ty, 256, 0, s>>>(labels, seeds_rc, h, w, tx, ty, tile_min, parent);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  k_union_tiles<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, parent, tile_min);
+  return hipGetLastError();
+}
+size_t union_image_tiles(int h, int w) { return (size_t)((w + UT - 1) / UT) * ((h + UT - 1) / UT); }
+
+// After the last union: every colour points straight at its root, so that relabelling is one gather.
+__global__ void k_uf_flatten(uint32_t *parent, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint32_t r = uf_find(parent, (uint32_t)i);
+    if (r != (uint32_t)i) atomicMin(parent + i, r);
+  }
+}
+
+// lib.rs:589-592 with the closed, flattened map, final level: uncoloured pixels carry label 0 and parent[0] == 0
+__global__ void k_relabel_flat(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ parent, uint32_t *out, size_t n) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  const bool vec = ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+  const size_t nv = vec ? n / 4 : 0;
+  for (size_t i = tid; i < nv; i += step) {
+    const u32x4_m l = reinterpret_cast<const u32x4_m *>(labels)[i];
+    reinterpret_cast<u32x4_m *>(out)[i] = u32x4_m{parent[l.x], parent[l.y], parent[l.z], parent[l.w]};
+  }
+  for (size_t i = nv * 4 + tid; i < n; i += step) out[i] = parent[labels[i]];
+}
+
+hipError_t relabel_final_u32(hipStream_t s, const uint32_t *labels, uint32_t *parent, size_t n_colours, uint32_t *out, size_t n) {
+  if (n == 0) return hipSuccess;
+  const int fb = (int)std::min<size_t>((n_colours + 255) / 256, 8192);
+  k_uf_flatten<<<fb > 0 ? fb : 1, 256, 0, s>>>(parent, n_colours);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 16384);
+  k_relabel_flat<<<blocks, 256, 0, s>>>(labels, parent, out, n);
   return hipGetLastError();
 }
 

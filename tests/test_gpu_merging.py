@@ -181,3 +181,28 @@ def test_merge_config3_8192_properties(pkg):
     # on a uniform random field the whole interior ends up as one lake with id 1... unless a border seed
     ids = torch.unique(mer64[1:-1, 1:-1])
     assert ids.numel() == 1
+
+
+@pytest.mark.parametrize("shape,edge", [((600, 700), False), ((512, 512), False), ((130, 70), False), ((64, 64), False),
+                                        ((65, 129), False), ((257, 193), True), ((66, 66), False), ((2, 300), False)])
+def test_merge_final_labels_full_level_border_and_corner_seeds(pkg, shape, edge):
+    # final level of a fully flooded field: nearly every tile is one lake (the one-lake tile path), seeds on
+    # the image border join through their inward neighbour, seeds on the four corners never join anything
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    h, w = shape
+    himg = cases.field(h, w, 31)
+    base = ol.find_local_minima(himg)
+    ph, pw = (h + 2, w + 2) if edge else (h, w)
+    extra = [(0, 0), (0, pw - 1), (ph - 1, 0), (ph - 1, pw - 1), (0, pw // 2), (ph - 1, pw // 3), (ph // 2, 0), (ph // 3, pw - 1),
+             (0, 1), (1, 0)]
+    extra = [(r, c) for r, c in extra if r < (ph if edge else h) and c < (pw if edge else w)]
+    hseeds = np.concatenate([base.reshape(-1, 2), np.array(extra, np.uint64).reshape(-1, 2)]).astype(np.uint64)
+    img = torch.from_numpy(himg).to(eng.device)
+    seeds = torch.from_numpy(hseeds.astype(np.int64)).to(eng.device).to(torch.int32)
+    got = eng.merge(img, seeds.contiguous(), edge=edge)
+    torch.cuda.synchronize()
+    want = ol.merge_arrival(himg, hseeds, edge=edge)
+    assert (got.cpu().numpy().view(np.uint32) == want).all()
