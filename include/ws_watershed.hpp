@@ -13,6 +13,7 @@
 // BuildErr> as a thrown BuildErr.  Documented deviations from the reference: see ws_hip.h.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -183,7 +184,9 @@ class Watershed : public WatershedUtils {  // lib.rs:1206-1238
     const std::size_t levels = std::size_t(opt_.max_water_level) + 1;
     std::vector<std::uint64_t> offsets(levels + 1), unc(levels);
     auto packed = detail::pack(seeds);
-    std::size_t cap = seeds.size() * 8 + 16, n = 0;
+    // one record per live lake and level, at most seeds * levels; half of that covers a random field.  A too
+    // small guess costs a second transform, not a wrong answer.
+    std::size_t cap = std::min<std::size_t>(seeds.size() * levels / 2 + 1024, std::size_t(1) << 26), n = 0;
     std::vector<ws_lake> lakes;
     for (;;) {
       lakes.resize(cap);

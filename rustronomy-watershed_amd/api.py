@@ -301,7 +301,9 @@ class _Transform(WatershedUtils):
         offsets = np.zeros(levels + 1, dtype=np.uint64)
         unc = np.zeros(levels, dtype=np.uint64)
         n = ctypes.c_size_t(0)
-        cap = max(ns, 1) * 8
+        # one record per live lake and level, at most ns * levels; half of that covers a random field (83 per seed
+        # at 1024^2).  A too small guess costs a second transform, not a wrong answer.
+        cap = min(max(ns, 1) * (self.max_water_level + 1) // 2 + 1024, 1 << 26)
         while True:
             lakes = np.empty((cap, 2), dtype=np.uint64)
             rc = _ffi.lib().ws_transform_to_list(ctx.handle, int(self._merging), a.ctypes.data, h, w, stride,
@@ -332,7 +334,9 @@ class _Transform(WatershedUtils):
         offsets = np.zeros(levels + 1, dtype=np.uint64)
         unc = np.zeros(levels, dtype=np.uint64)
         n = ctypes.c_size_t(0)
-        cap = max(ns, 1) * 8
+        # one record per live lake and level, at most ns * levels; half of that covers a random field (83 per seed
+        # at 1024^2).  A too small guess costs a second transform, not a wrong answer.
+        cap = min(max(ns, 1) * (self.max_water_level + 1) // 2 + 1024, 1 << 26)
         while True:
             lakes = np.empty((cap, 2), dtype=np.uint64)
             rc = _ffi.lib().ws_transform_to_list(ctx.handle, int(self._merging), a.ctypes.data, h, w, stride,
@@ -343,8 +347,9 @@ class _Transform(WatershedUtils):
                 continue
             ctx.check(rc)
             break
-        return [(lvl, int(unc[lvl]), lakes[int(offsets[lvl]):int(offsets[lvl + 1]), 0].copy(),
-                 lakes[int(offsets[lvl]):int(offsets[lvl + 1]), 1].copy()) for lvl in range(levels)]
+        # views into one record array (no per-level copies: 155 MB of them at 1024^2)
+        off = offsets.astype(np.int64)
+        return [(lvl, int(unc[lvl]), lakes[off[lvl]:off[lvl + 1], 0], lakes[off[lvl]:off[lvl + 1], 1]) for lvl in range(levels)]
 
 
 class SegmentingWatershed(_Transform):

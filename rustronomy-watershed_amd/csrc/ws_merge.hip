@@ -231,10 +231,25 @@ hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hoo
   return hipGetLastError();
 }
 
+// Areas of the pixels arriving at this level go to the lake they arrive in.  Late levels have few lakes,
+// so most lanes of a wave add to the SAME word: the wave adds once per distinct root (leader election by
+// ballot) -- same-address atomics retire one per ~12 ns, and 4000 of them were the whole kernel.
 __global__ void k_add_arrivals(const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) atomicAdd(&size[uf_find(parent, px_items[i])], 1u);
+  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < n; base += step) {      // uniform trip count per wave
+    const size_t i = base + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    while (todo != 0) {
+      const int leader = (int)__builtin_ctzll(todo);
+      const uint32_t r0 = __shfl(r, leader, 64);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
+      if (lane == leader) atomicAdd(&size[r0], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
+  }
 }
 
 hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size) {
