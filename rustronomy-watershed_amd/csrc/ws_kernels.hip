@@ -631,7 +631,8 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
                                                             const uint32_t *__restrict__ word_base) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
-  const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
+  const uint32_t tile = xcd_span_index(blockIdx.x, gridDim.x);
+  const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int pc = tid & 15, pr = tid >> 4;

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   // the first wave of workgroup 0 clears the next pass's convergence slot
   if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
     pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
-  const int first = CHUNKED ? (int)blockIdx.x * chunk : (int)blockIdx.x;
+  // (XCD-aware: consecutive workgroups go to different XCDs; see xcd_span_index)
+  const int first = (int)xcd_span_index(blockIdx.x, gridDim.x) * (CHUNKED ? chunk : 1);
   unsigned long long todo = 1;
   if (CHUNKED) {
     todo = relax_todo<NW>(first, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
