@@ -45,7 +45,7 @@ struct ws_ctx {
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
   DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab;
-  uint32_t *pinned = nullptr;      // COUNTER_RING + 4 words of pinned host memory
+  uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
   hipStream_t copy_stream = nullptr;    // carries the per-pass flag read-backs
@@ -192,14 +192,16 @@ int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *
 // one event record + one flag read-back (on a side stream) per group, not per pass -- an event
 // record between two dependent kernels costs ~10 us of dependency gap on this stack, a pass that
 // has nothing to do ~4 us.  The host stays one group ahead of the flags it reads, so the stream
-// never waits for a host round trip.  Flag slots live in a ring of COUNTER_RING passes (pass q clears
-// the slot of pass q + 1): first_group + GROUP passes in flight must stay below it.
-constexpr uint32_t PASS_GROUP = 2;
+// never waits for a host round trip.  Groups grow (2, 4, 8, 16): a smooth map needs hundreds of short
+// passes, and with groups of two the host's ~100 us of API calls per group was most of their time.
+// Flag slots live in a ring of COUNTER_RING passes (pass q clears the slot of pass q + 1): two groups
+// in flight must stay below it.
+constexpr uint32_t PASS_GROUP = 2, PASS_GROUP_MAX = 16;
 template <class F>
 int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch, bool zeroed = false,
               uint32_t first_group = 2) {
-  static_assert(5 + PASS_GROUP < COUNTER_RING, "groups in flight must fit the flag ring");
-  if (first_group > 5) first_group = 5;
+  static_assert(2 * PASS_GROUP_MAX < COUNTER_RING, "groups in flight must fit the flag ring");
+  if (first_group > PASS_GROUP_MAX) first_group = PASS_GROUP_MAX;
   if (!zeroed) {        // the tile-edge stamps and the convergence ring start at zero
     HIP_TRY(c, hipMemsetAsync(c->stamps.p, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_flags + FLAG_EDGE, 0, COUNTER_RING * FLAG_SLOT * sizeof(uint32_t), c->stream));
@@ -214,10 +216,12 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
     // the flag read-back rides a side stream: the next group never queues behind a copy
     HIP_TRY(c, hipEventRecord(c->kern_ev[g->ev], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g->ev], 0));
-    for (uint32_t p = g->lo; p < g->hi; ++p) {
-      const int slot = p % COUNTER_RING;
+    for (uint32_t p = g->lo; p < g->hi;) {      // the group's slots: one copy, two when they wrap around the ring
+      const uint32_t slot = p % COUNTER_RING;
+      const uint32_t run = std::min<uint32_t>(g->hi - p, COUNTER_RING - slot);
       HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_EDGE + slot * FLAG_SLOT], d_flags + FLAG_EDGE + slot * FLAG_SLOT,
-                                FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
+                                (size_t)run * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
+      p += run;
     }
     HIP_TRY(c, hipEventRecord(c->ring_ev[g->ev], c->copy_stream));
     return WS_OK;
@@ -225,14 +229,16 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   Group done{}, ahead{};
   int rc;
   if ((rc = launch_group(first_group, &done))) return rc;
+  uint32_t size = PASS_GROUP;
   for (;;) {
-    if ((rc = launch_group(PASS_GROUP, &ahead))) return rc;
+    if ((rc = launch_group(size, &ahead))) return rc;
     HIP_TRY(c, hipEventSynchronize(c->ring_ev[done.ev]));
     bool converged = false;
     for (uint32_t p = done.lo; p < done.hi && !converged; ++p)
       converged = !slot_nonzero(&c->pinned[FLAG_EDGE + (p % COUNTER_RING) * FLAG_SLOT]);
     if (converged) break;
     done = ahead;
+    size = std::min(size * 2, PASS_GROUP_MAX);
   }
   // later work on the main stream may reuse the flag words: order it after the last read-back
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring_ev[ahead.ev], 0));

@@ -118,13 +118,13 @@ __device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const u
 // first + k; the ballot is the to-do list.  tilesX x tilesY is this pass's grid, otherX x otherY the
 // grid of the previous pass.
 template <int NW>
-__device__ __forceinline__ unsigned long long relax_todo(int first, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
+__device__ __forceinline__ unsigned long long relax_todo(int first, int stride, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
                                                          int otherY, int shifted, uint32_t pass,
                                                          const uint32_t *__restrict__ stamps_prev) {
   constexpr int TH = NW * RX_P;
   const int lane = threadIdx.x & 63;
   const int ox = shifted ? RX_TW / 2 : 0, oy = shifted ? TH / 2 : 0;
-  const int t = first + lane;
+  const int t = first + lane * stride;
   const bool mine = lane < chunk && t < tilesX * tilesY;
   const int tx = mine ? t % tilesX : 0, ty = mine ? t / tilesX : 0;
   // a shifted grid can have a last row/column outside the plane
@@ -151,7 +151,53 @@ __device__ __forceinline__ unsigned long long relax_todo(int first, int chunk, i
 // CHUNKED = true: `chunk` (<= 64) consecutive tiles per workgroup, run one after the other -- the late
 // passes, in which few tiles run: a pass with nothing to do costs 1/chunk of the workgroup launches.
 // (One body for both, not a shared device function: at the 80-VGPR cap the out-of-line form spilled.)
-template <int NW, bool CHUNKED>
+// ---- long-range rows ---------------------------------------------------------------------------
+//
+// A column sweep moves information one patch (4 pixels) per round along a row, so a flood that has to
+// cross a 256-pixel tile sideways -- the normal case on a smooth map -- took 64 rounds per tile and pass.
+// The row recurrence  t_x <- min(t_x, max(b_x, t_{x-1} + 1))  is a chain of clamped increments
+// f_x(v) = med3(b_x, v + 1, t_x), and those compose:  (g o f)(v) = med3(lo, v + a, hi)  with
+//   a = a_f + a_g,  lo = med3(lo_g, lo_f + a_g, hi_g),  hi = med3(lo_g, hi_f + a_g, hi_g).
+// So the whole row is evaluated EXACTLY -- the same values the sequential sweep would give, pixel by
+// pixel, ring carries included -- by a 6-step inclusive scan over the lanes of the wave: each lane
+// reduces its 4 pixels to one (lo, hi, 4) triple, the scan composes triples, and every lane then knows
+// the value that enters it from its neighbour.  Used only from pass RX_SCAN_FROM_PASS on (the bench field
+// has converged by then; the scan costs registers, so the early passes run a variant without it) and
+// only for tiles that are still moving after RX_SCAN_AFTER rounds.
+constexpr uint32_t RX_SCAN_AFTER = 2;
+constexpr uint32_t RX_SCAN_FROM_PASS = 4;
+
+template <bool TRACK, bool RIGHT>
+__device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b)[RX_P], uint32_t halo_in, int lane, bool &changed) {
+  // pixels in sweep order
+  const uint32_t t0 = RIGHT ? t[0] : t[3], t1 = RIGHT ? t[1] : t[2], t2 = RIGHT ? t[2] : t[1], t3 = RIGHT ? t[3] : t[0];
+  const uint32_t b0 = RIGHT ? b[0] : b[3], b1 = RIGHT ? b[1] : b[2], b2 = RIGHT ? b[2] : b[1], b3 = RIGHT ? b[3] : b[0];
+  // this lane's four pixels as one function: its value for a huge and for a tiny argument
+  uint32_t hi = t0;
+  hi = med3u(b1, hi + 1u, t1); hi = med3u(b2, hi + 1u, t2); hi = med3u(b3, hi + 1u, t3);
+  uint32_t lo = b0;
+  lo = med3u(b1, lo + 1u, t1); lo = med3u(b2, lo + 1u, t2); lo = med3u(b3, lo + 1u, t3);
+  uint32_t add = RX_P;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {       // inclusive scan in sweep order: acc_i <- acc_i o acc_(i -/+ o)
+    const uint32_t plo = RIGHT ? __shfl_up(lo, o, 64) : __shfl_down(lo, o, 64);
+    const uint32_t phi = RIGHT ? __shfl_up(hi, o, 64) : __shfl_down(hi, o, 64);
+    const uint32_t padd = RIGHT ? __shfl_up(add, o, 64) : __shfl_down(add, o, 64);
+    const bool has = RIGHT ? lane >= o : lane + o < 64;
+    const uint32_t nlo = med3u(lo, plo + add, hi), nhi = med3u(lo, phi + add, hi);
+    lo = has ? nlo : lo;
+    hi = has ? nhi : hi;
+    add = has ? add + padd : add;
+  }
+  // the value that leaves this lane when `halo_in` enters the row, handed to the next lane
+  const uint32_t leaves = med3u(lo, halo_in + add, hi);
+  const uint32_t vin = RIGHT ? lane_left(halo_in, leaves) : lane_right(halo_in, leaves);
+  const uint32_t n0 = med3u(b0, vin + 1u, t0), n1 = med3u(b1, n0 + 1u, t1), n2 = med3u(b2, n1 + 1u, t2), n3 = med3u(b3, n2 + 1u, t3);
+  if (TRACK) changed |= (n0 != t0) | (n1 != t1) | (n2 != t2) | (n3 != t3);
+  t[RIGHT ? 0 : 3] = n0; t[RIGHT ? 1 : 2] = n1; t[RIGHT ? 2 : 1] = n2; t[RIGHT ? 3 : 0] = n3;
+}
+
+template <int NW, bool CHUNKED, bool SCAN>
 __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
@@ -177,10 +223,13 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
     pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
   // (XCD-aware: consecutive workgroups go to different XCDs; see xcd_span_index)
-  const int first = (int)xcd_span_index(blockIdx.x, gridDim.x) * (CHUNKED ? chunk : 1);
+  // A chunk is `chunk` tiles one grid size apart, not neighbours: on a smooth map the tiles that still
+  // run line up along a front, and four neighbours in one workgroup ran one after the other.
+  const int first = (int)xcd_span_index(blockIdx.x, gridDim.x);
+  const int stride = (int)gridDim.x;
   unsigned long long todo = 1;
   if (CHUNKED) {
-    todo = relax_todo<NW>(first, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
+    todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
     if (todo == 0) return;
   } else {
     const int tx = first % tilesX, ty = first / tilesX;
@@ -205,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   int tid = threadIdx.x;
   if (CHUNKED) asm volatile("" : "+v"(tid));
   const int lane = tid & 63, band = tid >> 6;
-  const int tile = CHUNKED ? first + (int)__builtin_ctzll(todo) : first;
+  const int tile = CHUNKED ? first + (int)__builtin_ctzll(todo) * stride : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = tile_x * RX_TW - (shifted ? RX_TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
@@ -364,9 +413,18 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
     sweep_cols<false, true>(T, B, up, dn, L, R, untracked);       // right
+    const bool long_range = SCAN && iters > RX_SCAN_AFTER;        // workgroup uniform
+    if (long_range) {
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(halo[r], 0, 64), lane, untracked);
+    }
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
     sweep_rows<false, false>(T, B, up, dn, L, R, untracked);      // up
+    if (long_range) {
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r) scan_row<false, false>(T[r], B[r], __shfl(halo[r], 63, 64), lane, untracked);
+    }
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
     *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
     __syncthreads();
@@ -504,14 +562,20 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     const char *e = getenv("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 3u;
   }();
+  const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
+  const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from) {
-    k_relax<RX_NW, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                         prev, cur, pf, max_iters, pass == 0 ? seed_labels : nullptr,
-                                                         pass == 0 && seed_labels && seed_bits ? 1 : 0);
+    k_relax<RX_NW, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
+                                                                prev, cur, pf, max_iters, sl, sb);
   } else {
     const int chunk = 4;
-    k_relax<RX_NW, true><<<(tx * ty + chunk - 1) / chunk, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted,
-                                                                              chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0);
+    const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
+    if (pass < RX_SCAN_FROM_PASS)
+      k_relax<RX_NW, true, false><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0);
+    else
+      k_relax<RX_NW, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0);
   }
   return hipGetLastError();
 }
