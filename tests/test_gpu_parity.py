@@ -304,3 +304,21 @@ def test_seed_painting_sorted_duplicated_and_shuffled_lists(pkg, shape):
     with pytest.raises(IndexError):
         ws.transform(img, bad)
     assert (ws.transform(img, base) == ol.segment_arrival(img, base)).all()         # and the context recovers
+
+
+# ---- long-range floods: the whole-row scan of the late relaxation passes ---------------------------------
+
+@pytest.mark.parametrize("shape,octaves,few_seeds", [((1100, 1600), 6, False), ((900, 2048), 7, True), ((700, 1030), 5, True)])
+def test_segment_large_smooth_fields_long_range(pkg, shape, octaves, few_seeds):
+    # correlation lengths of 64-256 pixels: floods cross many tiles, dozens to hundreds of passes; with only
+    # a handful of seeds a single flood crosses the whole plane
+    img = cases.smooth_field(*shape, 17, octaves=octaves)
+    seeds = ol.find_local_minima(img)
+    if few_seeds:
+        seeds = seeds[:: max(len(seeds) // 5, 1)][:5]
+    ws = _seg(pkg, pkg.ENGINE_FUSED)
+    got = ws.transform(img, seeds)
+    want = ol.segment_arrival(img, seeds)
+    assert got.shape == want.shape and (got == want).all()
+    st = ws._ctx().stats()
+    assert st["relax_passes"] >= 8           # the scan-capable kernel variant ran (passes >= 4)
