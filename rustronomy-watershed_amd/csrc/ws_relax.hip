@@ -197,8 +197,54 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
   t[RIGHT ? 0 : 3] = n0; t[RIGHT ? 1 : 2] = n1; t[RIGHT ? 2 : 1] = n2; t[RIGHT ? 3 : 0] = n3;
 }
 
+// The same idea down the columns of a tile: the rows of a column live in NW different waves, so every
+// band publishes its four rows of each column as one function in LDS, and a band composes the bands
+// above (below) it -- at most NW - 1 of them -- onto the tile's halo row to get the value that enters
+// its own rows.  Exact, like the row scan; two barriers.
+template <int NW, bool DOWN>
+__device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_row, int band, int lane) {      // fn: [NW][2][RX_TW]
+  u32x4_t lo4, hi4;
+  uint32_t lo[RX_P], hi[RX_P];
+#pragma unroll
+  for (int c = 0; c < RX_P; ++c) {
+    uint32_t h = T[DOWN ? 0 : 3][c], l = B[DOWN ? 0 : 3][c];
+#pragma unroll
+    for (int k = 1; k < RX_P; ++k) {
+      const int r = DOWN ? k : RX_P - 1 - k;
+      h = med3u(B[r][c], h + 1u, T[r][c]);
+      l = med3u(B[r][c], l + 1u, T[r][c]);
+    }
+    lo[c] = l; hi[c] = h;
+  }
+  lo4 = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+  hi4 = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 0) * RX_TW + lane * RX_P]) = lo4;
+  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 1) * RX_TW + lane * RX_P]) = hi4;
+  __syncthreads();
+  const u32x4_t h4 = *reinterpret_cast<const u32x4_t *>(&halo_row[lane * RX_P]);
+  uint32_t v[RX_P] = {h4.x, h4.y, h4.z, h4.w};
+  for (int k = DOWN ? 0 : NW - 1; DOWN ? k < band : k > band; k += DOWN ? 1 : -1) {      // wave uniform
+    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * RX_TW + lane * RX_P]);
+    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * RX_TW + lane * RX_P]);
+    v[0] = med3u(l4.x, v[0] + RX_P, g4.x); v[1] = med3u(l4.y, v[1] + RX_P, g4.y);
+    v[2] = med3u(l4.z, v[2] + RX_P, g4.z); v[3] = med3u(l4.w, v[3] + RX_P, g4.w);
+  }
+#pragma unroll
+  for (int c = 0; c < RX_P; ++c) {
+    uint32_t n = v[c];
+#pragma unroll
+    for (int k = 0; k < RX_P; ++k) {
+      const int r = DOWN ? k : RX_P - 1 - k;
+      n = med3u(B[r][c], n + 1u, T[r][c]);
+      T[r][c] = n;
+    }
+  }
+  __syncthreads();          // the functions are rebuilt by the next call
+}
+
 template <int NW, bool CHUNKED, bool SCAN>
-__global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
+__global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
+const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
@@ -217,6 +263,8 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
   // __syncthreads_or costs
   __shared__ uint32_t s_flag[3];
   __shared__ uint64_t s_sum[64 * NW];        // per-lane patch checksum taken at load time (parked: VGPRs are at the cap)
+  // long-range columns (SCAN): every band's four rows of a column as one clamped increment (lo, hi)
+  __shared__ __attribute__((aligned(16))) uint32_t sFn[SCAN ? NW : 1][2][SCAN ? RX_TW : 4];
 
 
   // the first wave of workgroup 0 clears the next pass's convergence slot
@@ -417,6 +465,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     if (long_range) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(halo[r], 0, 64), lane, untracked);
+      scan_cols<NW, true>(T, B, &sFn[0][0][0], sRow[0], band, lane);
     }
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
@@ -424,6 +473,7 @@ __global__ __launch_bounds__(64 * NW, 6) void k_relax(const uint8_t *__restrict_
     if (long_range) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, false>(T[r], B[r], __shfl(halo[r], 63, 64), lane, untracked);
+      scan_cols<NW, false>(T, B, &sFn[0][0][0], sRow[2 * NW + 1], band, lane);
     }
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
     *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
