@@ -615,11 +615,13 @@ int ws_find_local_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_
   const size_t nseg = minima_segments((int)h, (int)w);
   int rc;
   if ((rc = ensure(c, c->counts, nseg * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->aux, minima_mask_bytes((int)h, (int)w)))) return rc;
   uint32_t *counts = (uint32_t *)c->counts.p;
+  uint8_t *nibbles = (uint8_t *)c->aux.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
-  HIP_TRY(c, minima_count(c->stream, d_img, stride, (int)h, (int)w, counts));
+  HIP_TRY(c, minima_count(c->stream, d_img, stride, (int)h, (int)w, counts, nibbles));
   HIP_TRY(c, exclusive_scan_u32(c->stream, counts, nseg, flags + FLAG_TOTAL));
-  HIP_TRY(c, minima_write(c->stream, d_img, stride, (int)h, (int)w, counts, d_out_rc, cap));
+  HIP_TRY(c, minima_write(c->stream, nibbles, (int)h, (int)w, counts, d_out_rc, cap));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TOTAL], flags + FLAG_TOTAL, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *n_found = c->pinned[FLAG_TOTAL];

@@ -976,51 +976,72 @@ hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, cons
 
 // ---------------------------------------------------------- find_local_minima --------
 //
-// lib.rs:1178-1197: interior pixels whose 8 neighbours are all strictly smaller, emitted
-// in row-major order.  Two passes over 1024-pixel row segments (256 threads x 4 px):
-// count, exclusive scan of the segment counts, then an ordered write.
+// lib.rs:1178-1197: interior pixels whose 8 neighbours are all strictly smaller, emitted in row-major
+// order.  One workgroup per image row, 4 pixels per thread and step: the count pass also leaves the
+// 4-bit answer of every thread-step in a nibble plane, so that the ordered write (after an exclusive scan
+// of the per-row counts) does not read the image again.
 
-constexpr int SEG = 1024;
+constexpr int SEG = 1024;            // pixels per workgroup step: 256 threads x 4
 
-size_t minima_segments(int h, int w) { return (size_t)h * ((w + SEG - 1) / SEG); }
+size_t minima_segments(int h, int w) { return (size_t)h; }                                    // one count per row
+size_t minima_mask_bytes(int h, int w) { return (size_t)h * ((w + SEG - 1) / SEG) * 256; }    // one nibble byte per thread-step
 
-__device__ __forceinline__ uint32_t maxima_mask4(const uint8_t *img, size_t stride, int H, int W, int y, int x0) {
-  // bit k set when pixel (y, x0+k) is a strict 8-neighbour maximum of the interior
-  uint32_t m = 0;
-  if (y < 1 || y >= H - 1) return 0;
-  const uint8_t *rm = img + (size_t)(y - 1) * stride, *r0 = img + (size_t)y * stride, *rp = img + (size_t)(y + 1) * stride;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = x0 + k;
-    if (x >= 1 && x < W - 1) {
-      const uint8_t v = r0[x];
-      const bool ok = rm[x - 1] < v && rm[x] < v && rm[x + 1] < v && r0[x - 1] < v && r0[x + 1] < v &&
-                      rp[x - 1] < v && rp[x] < v && rp[x + 1] < v;
-      m |= ok ? (1u << k) : 0u;
-    }
+// the six pixels x0-1 .. x0+4 of one row as bytes of a 64-bit word (clamped at the row ends: a clamped
+// byte only ever meets a pixel that is not interior)
+__device__ __forceinline__ unsigned long long row_window(const uint8_t *row, int W, int x0, bool fast) {
+  if (fast) {      // x0 >= 4, x0 + 8 <= W, dword-aligned row: three aligned loads, unconditional
+    const uint32_t p = *reinterpret_cast<const uint32_t *>(row + x0 - 4), c = *reinterpret_cast<const uint32_t *>(row + x0),
+                   n = *reinterpret_cast<const uint32_t *>(row + x0 + 4);
+    return (unsigned long long)(p >> 24) | ((unsigned long long)c << 8) | ((unsigned long long)(n & 0xFFu) << 40);
   }
-  return m;
+  unsigned long long w = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) w |= (unsigned long long)row[min(max(x0 - 1 + k, 0), W - 1)] << (8 * k);
+  return w;
+}
+
+// bit k set when pixel (y, x0+k) is a strict 8-neighbour maximum of the interior; 1 <= y <= H-2
+__device__ __forceinline__ uint32_t maxima_mask4(const uint8_t *img, size_t stride, int W, int y, int x0, bool aligned) {
+  const bool fast = aligned && x0 >= 4 && x0 + 8 <= W;
+  const int xc = min(x0, max(W - 1, 0));
+  const unsigned long long t = row_window(img + (size_t)(y - 1) * stride, W, xc, fast);
+  const unsigned long long m = row_window(img + (size_t)y * stride, W, xc, fast);
+  const unsigned long long b = row_window(img + (size_t)(y + 1) * stride, W, xc, fast);
+  uint32_t tb[6], mb[6], bb[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { tb[k] = (uint32_t)(t >> (8 * k)) & 0xFFu; mb[k] = (uint32_t)(m >> (8 * k)) & 0xFFu; bb[k] = (uint32_t)(b >> (8 * k)) & 0xFFu; }
+  uint32_t mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {      // branch-free: max of the 8 neighbours, one compare
+    const uint32_t nb = max(max(max(tb[k], tb[k + 1]), max(tb[k + 2], mb[k])), max(max(mb[k + 2], bb[k]), max(bb[k + 1], bb[k + 2])));
+    const int x = x0 + k;
+    mask |= (uint32_t)((mb[k + 1] > nb) & (x >= 1) & (x < W - 1)) << k;
+  }
+  return mask;
 }
 
 __global__ __launch_bounds__(256) void k_minima_count(const uint8_t *__restrict__ img, size_t stride, int H, int W,
-                                                      int segs, uint32_t *counts) {
-  __shared__ uint32_t s_sum;
-  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
-  if (threadIdx.x == 0) s_sum = 0;
-  __syncthreads();
-  const uint32_t m = maxima_mask4(img, stride, H, W, y, seg * SEG + threadIdx.x * 4);
-  uint32_t c = __popc(m);
-  // wave reduction, then one LDS atomic per wave
+                                                      uint32_t *counts, uint8_t *nibbles) {
+  __shared__ uint32_t s_wave[4];
+  const int y = blockIdx.x, segs = (W + SEG - 1) / SEG;
+  const bool row_ok = y >= 1 && y < H - 1;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(img) | stride) & 3u) == 0;
+  uint32_t c = 0;
+  for (int seg = 0; seg < segs; ++seg) {
+    const int x0 = seg * SEG + threadIdx.x * 4;
+    const uint32_t m = (row_ok && x0 < W) ? maxima_mask4(img, stride, W, y, x0, aligned) : 0u;
+    nibbles[((size_t)y * segs + seg) * 256 + threadIdx.x] = (uint8_t)m;
+    c += __popc(m);
+  }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) counts[blockIdx.x] = s_sum;
+  if (threadIdx.x == 0) counts[y] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
-hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts) {
-  const int segs = (w + SEG - 1) / SEG;
+hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts, uint8_t *nibbles) {
   if (h == 0 || w == 0) return hipSuccess;
-  k_minima_count<<<h * segs, 256, 0, s>>>(img, stride, h, w, segs, counts);
+  k_minima_count<<<h, 256, 0, s>>>(img, stride, h, w, counts, nibbles);
   return hipGetLastError();
 }
 
@@ -1050,40 +1071,43 @@ hipError_t exclusive_scan_u32(hipStream_t s, uint32_t *data, size_t n, uint32_t 
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict__ img, size_t stride, int H, int W,
-                                                      int segs, const uint32_t *__restrict__ offsets,
-                                                      uint32_t *out_rc, size_t cap) {
+__global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict__ nibbles, int H, int W,
+                                                      const uint32_t *__restrict__ offsets, uint32_t *out_rc, size_t cap) {
   __shared__ uint32_t s_wave[4];
-  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
-  const int x0 = seg * SEG + threadIdx.x * 4;
-  const uint32_t m = maxima_mask4(img, stride, H, W, y, x0);
-  const uint32_t c = __popc(m);
-  // exclusive prefix of c inside the wave, then across the 4 waves
-  uint32_t incl = c;
+  const int y = blockIdx.x, segs = (W + SEG - 1) / SEG;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint32_t wave_base = 0;
-  for (int k = 0; k < wave; ++k) wave_base += s_wave[k];
-  size_t pos = (size_t)offsets[blockIdx.x] + wave_base + (incl - c);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if ((m >> k) & 1u) {
-      if (pos < cap) { out_rc[2 * pos] = (uint32_t)y; out_rc[2 * pos + 1] = (uint32_t)(x0 + k); }
-      ++pos;
+  size_t row_pos = offsets[y];
+  for (int seg = 0; seg < segs; ++seg) {
+    const int x0 = seg * SEG + threadIdx.x * 4;
+    const uint32_t m = nibbles[((size_t)y * segs + seg) * 256 + threadIdx.x];
+    const uint32_t c = __popc(m);
+    // exclusive prefix of c inside the wave, then across the 4 waves
+    uint32_t incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
     }
+    __syncthreads();                               // s_wave of the previous step has been read
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { wave_base += k < wave ? s_wave[k] : 0u; total += s_wave[k]; }
+    size_t pos = row_pos + wave_base + (incl - c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((m >> k) & 1u) {
+        if (pos < cap) *reinterpret_cast<uint2 *>(out_rc + 2 * pos) = make_uint2((uint32_t)y, (uint32_t)(x0 + k));
+        ++pos;
+      }
+    }
+    row_pos += total;
   }
 }
 
-hipError_t minima_write(hipStream_t s, const uint8_t *img, size_t stride, int h, int w,
-                        const uint32_t *offsets, uint32_t *out_rc, size_t cap) {
-  const int segs = (w + SEG - 1) / SEG;
+hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *offsets, uint32_t *out_rc, size_t cap) {
   if (h == 0 || w == 0) return hipSuccess;
-  k_minima_write<<<h * segs, 256, 0, s>>>(img, stride, h, w, segs, offsets, out_rc, cap);
+  k_minima_write<<<h, 256, 0, s>>>(nibbles, h, w, offsets, out_rc, cap);
   return hipGetLastError();
 }
 
