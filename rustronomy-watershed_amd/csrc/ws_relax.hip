@@ -85,19 +85,20 @@ __device__ __forceinline__ uint32_t plane_or_bit(const uint32_t *src, size_t p, 
 
 typedef uint32_t patch_t[RX_P][RX_P];
 
-// A sweep updates a whole patch row (or column) at a time: its 4 pixels are independent (they use
-// the row's old left/right values), rows (columns) follow each other Gauss-Seidel fashion.
+// A sweep walks the patch rows (or columns) in its direction and, inside a row, the pixels left to right
+// (top to bottom), every pixel seeing its neighbours as they are NOW -- Gauss-Seidel all the way.  (Any
+// order is a valid relaxation; taking a row's "old" left/right values instead cost 40 register copies
+// per round.)
 template <bool TRACK, bool DOWN>
 __device__ __forceinline__ void sweep_rows(patch_t &T, const patch_t &B, const uint32_t (&up)[RX_P], const uint32_t (&dn)[RX_P],
                                            const uint32_t (&L)[RX_P], const uint32_t (&R)[RX_P], bool &changed) {
 #pragma unroll
   for (int k = 0; k < RX_P; ++k) {
     const int r = DOWN ? k : RX_P - 1 - k;
-    const uint32_t o0 = T[r][0], o1 = T[r][1], o2 = T[r][2], o3 = T[r][3];
-    const uint32_t ol[RX_P] = {L[r], o0, o1, o2}, orr[RX_P] = {o1, o2, o3, R[r]};
 #pragma unroll
     for (int c = 0; c < RX_P; ++c)
-      relax_px<TRACK>(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c], ol[c], orr[c], changed);
+      relax_px<TRACK>(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c],
+                      c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1], changed);
   }
 }
 template <bool TRACK, bool RIGHT>
@@ -106,11 +107,10 @@ __device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const u
 #pragma unroll
   for (int k = 0; k < RX_P; ++k) {
     const int c = RIGHT ? k : RX_P - 1 - k;
-    const uint32_t o0 = T[0][c], o1 = T[1][c], o2 = T[2][c], o3 = T[3][c];
-    const uint32_t ou[RX_P] = {up[c], o0, o1, o2}, od[RX_P] = {o1, o2, o3, dn[c]};
 #pragma unroll
     for (int r = 0; r < RX_P; ++r)
-      relax_px<TRACK>(T[r][c], B[r][c], ou[r], od[r], c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1], changed);
+      relax_px<TRACK>(T[r][c], B[r][c], r == 0 ? up[c] : T[r - 1][c], r == RX_P - 1 ? dn[c] : T[r + 1][c],
+                      c == 0 ? L[r] : T[r][c - 1], c == RX_P - 1 ? R[r] : T[r][c + 1], changed);
   }
 }
 
