@@ -43,3 +43,39 @@ def test_random_small_cases_bit_exact():
                 mer.enable_edge_correction()
             got = mer.build_merging().transform_final(img, seeds)
             assert (got == ol.merge_arrival(img, seeds, max_level=max_level, edge=edge)).all(), (case, "merge")
+
+
+def test_random_medium_cases_seed_forms_and_merging():
+    """Multi-tile shapes, against the arrival-form oracle: sorted-unique seed lists (side tables), the same lists
+    shuffled or with duplicates (painted plane) on ONE context so that the prediction flips back and forth, and
+    the merging transform's final labels at full and partial water levels (one-lake tiles and the general path)."""
+    ge.build_hip()
+    pkg = ge.load_package()
+    rng = np.random.default_rng(77)
+    for case in range(48):
+        h = int(rng.integers(3, 420))
+        w = int(rng.integers(1, 200)) * 4 if case % 4 else int(rng.integers(3, 800))      # mostly W % 4 == 0 (table form allowed)
+        kind = case % 3
+        if kind == 0:
+            img = rng.integers(0, 254, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            img = (rng.integers(0, 6, (h, w), dtype=np.uint8) * 40).astype(np.uint8)
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = ((np.sin(yy / 17.0) + np.cos(xx / 23.0) + 2.0) * 60 + rng.integers(0, 5, (h, w))).astype(np.uint8)
+        n_seeds = int(rng.integers(1, max(2, h * w // 40)))
+        flat = np.sort(rng.choice(h * w, size=min(n_seeds, h * w), replace=False))
+        seeds = np.stack([flat // w, flat % w], axis=1).astype(np.uint64)                    # strictly increasing, row-major
+        form = case % 3
+        if form == 1:
+            seeds = seeds[rng.permutation(len(seeds))]
+        elif form == 2:
+            seeds = np.concatenate([seeds, seeds[:: 3]])                                     # sorted part + duplicates at the end
+        max_level = int(rng.choice([254, 254, 100, 31]))
+        b = pkg.TransformBuilder.new().set_max_water_lvl(max_level).set_engine(pkg.ENGINE_FUSED)
+        got = b.build_segmenting().transform(img, seeds)
+        want = ol.segment_arrival(img, seeds, max_level=max_level)
+        assert got.shape == want.shape and (got == want).all(), ("segment", case, h, w, kind, form, max_level)
+        if case % 2 == 0:
+            got = pkg.TransformBuilder.new().set_max_water_lvl(max_level).build_merging().transform_final(img, seeds)
+            assert (got == ol.merge_arrival(img, seeds, max_level=max_level)).all(), ("merge", case, h, w, kind, form, max_level)
