@@ -195,6 +195,15 @@ int ws_find_local_minima_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, siz
 int ws_segment_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                       const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
                       uint32_t *d_labels);
+/* A stack of independent slices (BASELINE config C4: a cube cut into 2-D slices, as the reference's own
+ * integration tests do, tests/integration.rs:267,356): slice k starts at d_cube + k * slice_stride, its
+ * seeds are d_seeds_rc[2 * seed_offsets[k] .. 2 * seed_offsets[k+1]) (seed_offsets: n_slices + 1 entries, on
+ * the HOST), its labels go to d_labels + k * (padded plane).  Equivalent to n_slices calls of
+ * ws_segment_device; stops at the first slice that fails and reports its index in *failed_slice. */
+int ws_segment_batch_device(ws_ctx *ctx, const uint8_t *d_cube, size_t n_slices, size_t h, size_t w,
+                            size_t row_stride, size_t slice_stride, const uint32_t *d_seeds_rc,
+                            const size_t *seed_offsets, const ws_options *opt, uint32_t *d_labels,
+                            size_t *failed_slice);
 /* Merging transform, final canonical labels only. */
 int ws_merge_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                     const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,

@@ -1005,6 +1005,23 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
 extern "C" {
 
 // Final canonical labels only: one union pass over the whole image, no level buckets.
+int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, size_t h, size_t w, size_t stride,
+                            size_t slice_stride, const uint32_t *d_seeds_rc, const size_t *seed_offsets,
+                            const ws_options *opt, uint32_t *d_labels, size_t *failed_slice) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (failed_slice) *failed_slice = 0;
+  if (n_slices && (!seed_offsets || !opt)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (n_slices > 1 && slice_stride < h * stride) return fail(c, WS_ERR_BAD_ARG, "slice_stride < h * row_stride");
+  const size_t e = opt && opt->edge_correction ? 2 : 0, plane = (h + e) * (w + e);
+  for (size_t k = 0; k < n_slices; ++k) {
+    if (seed_offsets[k + 1] < seed_offsets[k]) return fail(c, WS_ERR_BAD_ARG, "seed_offsets must not decrease");
+    const int rc = ws_segment_device(c, d_cube + k * slice_stride, h, w, stride, d_seeds_rc + 2 * seed_offsets[k],
+                                     seed_offsets[k + 1] - seed_offsets[k], opt, d_labels + k * plane);
+    if (rc != WS_OK) { if (failed_slice) *failed_slice = k; return rc; }
+  }
+  return WS_OK;
+}
+
 int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
                     size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
   if (!c) return WS_ERR_BAD_ARG;

@@ -58,6 +58,24 @@ class DeviceEngine:
                                                     out.data_ptr()))
         return out
 
+    def segment_batch(self, cube, seeds, seed_offsets, max_level=254, edge=False, out=None):
+        """A stack of independent slices (config C4).  cube: (S, H, W) uint8; seeds: all slices' (row, col) pairs
+        concatenated, int32 (n, 2); seed_offsets: S + 1 host integers.  Returns (S, H', W') int32 labels."""
+        assert cube.dtype == torch.uint8 and cube.dim() == 3 and cube.is_contiguous() and cube.is_cuda
+        assert seeds.dtype == torch.int32 and seeds.is_cuda and (seeds.numel() == 0 or seeds.is_contiguous())
+        s, h, w = cube.shape
+        assert len(seed_offsets) == s + 1
+        e = 2 if edge else 0
+        if out is None:
+            out = torch.empty((s, h + e, w + e), dtype=torch.int32, device=self.device)
+        opt = self.options(max_level, edge)
+        offs = (ctypes.c_size_t * (s + 1))(*[int(x) for x in seed_offsets])
+        failed = ctypes.c_size_t(0)
+        self.ctx.check(_ffi.lib().ws_segment_batch_device(self.ctx.handle, cube.data_ptr(), s, h, w, w, h * w,
+                                                          seeds.data_ptr() if seeds.numel() else None, offs,
+                                                          ctypes.byref(opt), out.data_ptr(), ctypes.byref(failed)))
+        return out
+
     def merge(self, img, seeds, max_level=254, edge=False, out=None):
         assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
         h, w = img.shape

@@ -322,3 +322,21 @@ def test_segment_large_smooth_fields_long_range(pkg, shape, octaves, few_seeds):
     assert got.shape == want.shape and (got == want).all()
     st = ws._ctx().stats()
     assert st["relax_passes"] >= 8           # the scan-capable kernel variant ran (passes >= 4)
+
+
+def test_segment_batch_of_independent_slices(pkg):
+    # config C4 in miniature: a cube of slices, one call; equal to slice-by-slice calls and to the oracle
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    s, h, w = 5, 96, 200
+    himgs = [cases.field(h, w, 40 + k) if k % 2 == 0 else cases.smooth_field(h, w, 40 + k) for k in range(s)]
+    hseeds = [ol.find_local_minima(a) for a in himgs]
+    hseeds[3] = hseeds[3][:0]                                            # a slice without seeds
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
+    cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
+    allseeds = torch.from_numpy(np.concatenate(hseeds).astype(np.int64).reshape(-1, 2)).to(torch.int32).to(eng.device).contiguous()
+    got = eng.segment_batch(cube, allseeds, offs).cpu().numpy().view(np.uint32)
+    for k in range(s):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
