@@ -801,38 +801,42 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       }
     }
   }
-  // every pointer is final and in registers: the tile now becomes the painted colours, so that the
-  // colour of an in-tile root (a seed) is one LDS read
+  // every pointer is final and in registers: the tile now becomes COLOURS -- a pixel's own colour (a seed's, or
+  // none), and in the halo ring a REFERENCE to the global pixel the cell stands for -- so that whatever a
+  // pointer ends at, the answer is one unconditional LDS read of its target: no decode of the cell index, no
+  // select chain, no branch (this phase was 39 instructions per pixel with them)
+  {
+    const int side = tid >> 6, t = tid & 63;
+    const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
+    const int hx = side == 2 ? x0 - 1 : (side == 3 ? x0 + TS : x0 + t);
+    const int hyc = min(max(hy, 0), H - 1), hxc = min(max(hx, 0), W - 1);
+    sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = REF_BIT | (uint32_t)((size_t)hyc * W + hxc);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{Lb[r][0], Lb[r][1], Lb[r][2], Lb[r][3]};
   __syncthreads();
 
   uint32_t refmask = 0;                          // pixels whose chain leaves the tile
-  const uint32_t g_origin = (uint32_t)((size_t)(y0 - 1) * W + x0 - RL_X0);      // global index of LDS cell (0, 0); n < 2^31, wraps harmlessly
+  uint32_t out[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[r][c] = sB[P[r][c] & (RL_HALO - 1u)];      // 16 independent reads, one wait
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gy = gy0 + r;
-    uint32_t out[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
-      const uint32_t pv = P[r][c];
-      const uint32_t t = pv & (RL_HALO - 1u);
-      const bool leaves = (pv & RL_HALO) != 0u;
-      const uint32_t rly = t / RL_P, rlx = t - rly * RL_P;
-      const uint32_t rg = g_origin + rly * (uint32_t)W + rlx;
-      out[c] = t == cell ? Lb[r][c] : (leaves ? (REF_BIT | rg) : sB[t]);      // the root's colour is one LDS read
-      if (leaves && gy < H && gx0 + c < W) refmask |= 1u << (r * 4 + c);
-    }
+    for (int c = 0; c < 4; ++c)
+      refmask |= ((uint32_t)((out[r][c] & REF_BIT) != 0u) & (uint32_t)(gy < H) & (uint32_t)(gx0 + c < W)) << (r * 4 + c);
     if (gy < H) {
       if (vec) {
-        if (gx0 < W) *reinterpret_cast<u32x4_r *>(labels + (size_t)gy * W + gx0) = u32x4_r{out[0], out[1], out[2], out[3]};
+        if (gx0 < W) *reinterpret_cast<u32x4_r *>(labels + (size_t)gy * W + gx0) = u32x4_r{out[r][0], out[r][1], out[r][2], out[r][3]};
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (gx0 + c < W && (TABLES || (P[r][c] & (RL_HALO - 1u)) != (uint32_t)((ly0 + r) * RL_P + lx0 + c)))
-            labels[(size_t)gy * W + gx0 + c] = out[c];
+            labels[(size_t)gy * W + gx0 + c] = out[r][c];
       }
     }
   }
