@@ -192,11 +192,11 @@ int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *
 // one event record + one flag read-back (on a side stream) per group, not per pass -- an event
 // record between two dependent kernels costs ~10 us of dependency gap on this stack, a pass that
 // has nothing to do ~4 us.  The host stays one group ahead of the flags it reads, so the stream
-// never waits for a host round trip.  Groups grow (2, 4, 8, 16): a smooth map needs hundreds of short
+// never waits for a host round trip.  Groups grow (1, 2, 4, 8, 16): a smooth map needs hundreds of short
 // passes, and with groups of two the host's ~100 us of API calls per group was most of their time.
 // Flag slots live in a ring of COUNTER_RING passes (pass q clears the slot of pass q + 1): two groups
 // in flight must stay below it.
-constexpr uint32_t PASS_GROUP = 2, PASS_GROUP_MAX = 16;
+constexpr uint32_t PASS_GROUP_MAX = 16;
 template <class F>
 int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch, bool zeroed = false,
               uint32_t first_group = 2) {
@@ -229,7 +229,7 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   Group done{}, ahead{};
   int rc;
   if ((rc = launch_group(first_group, &done))) return rc;
-  uint32_t size = PASS_GROUP;
+  uint32_t size = 1;          // the first lookahead group: one pass is enough to keep the stream busy while the host reads
   for (;;) {
     if ((rc = launch_group(size, &ahead))) return rc;
     HIP_TRY(c, hipEventSynchronize(c->ring_ev[done.ev]));
