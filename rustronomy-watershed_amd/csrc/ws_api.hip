@@ -851,8 +851,10 @@ constexpr int MF_CUR_PX = 2 * NLEVELS;
 constexpr int MF_CUR_ED = 3 * NLEVELS;
 constexpr int MF_LAKE_CURSOR = 4 * NLEVELS;
 constexpr int MF_LAKE_OFFSETS = 4 * NLEVELS + 8;          // NLEVELS + 1 entries
-constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // u32 counter lives in this word
-constexpr int MF_WORDS = 5 * NLEVELS + 24;
+constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // NLEVELS u32 counters (one per level: no memset between levels)
+constexpr int MF_LAKE_COUNT = 6 * NLEVELS + 16;           // NLEVELS u64 per-level record counters
+constexpr int MF_LAKE_DONE = 7 * NLEVELS + 16;            // NLEVELS u32 finished-workgroup counters
+constexpr int MF_WORDS = 8 * NLEVELS + 24;
 
 struct LevelBuckets {
   std::vector<uint64_t> off_px, off_ed;    // NLEVELS + 1 prefix sums
@@ -908,9 +910,8 @@ int level_loop(ws_ctx *c, const LevelBuckets &lb, uint32_t max_level, bool mergi
   for (uint32_t l = 0; l <= max_level; ++l) {
     const size_t e0 = lb.off_ed[l], e1 = lb.off_ed[l + 1], p0 = lb.off_px[l], p1 = lb.off_px[l + 1];
     if (merging && e1 > e0) {
-      HIP_TRY(c, hipMemsetAsync(hooked_count, 0, sizeof(uint32_t), c->stream));
-      HIP_TRY(c, union_edges(c->stream, edge_items + e0, e1 - e0, parent, want_sizes ? hooked : nullptr, hooked_count));
-      if (want_sizes) HIP_TRY(c, fold_sizes(c->stream, hooked, hooked_count, parent, size));
+      HIP_TRY(c, union_edges(c->stream, edge_items + e0, e1 - e0, parent, want_sizes ? hooked : nullptr, hooked_count + l));
+      if (want_sizes) HIP_TRY(c, fold_sizes(c->stream, hooked, hooked_count + l, parent, size));
       c->stats.merge_levels++;
     }
     if (want_sizes && p1 > p0) HIP_TRY(c, add_arrivals(c->stream, px_items + p0, p1 - p0, parent, size));
@@ -957,16 +958,16 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     if ((rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(c, c->mflags, MF_WORDS * sizeof(uint64_t)))) return rc;
     mf = (u64c *)c->mflags.p;
-    HIP_TRY(c, hipMemsetAsync(mf + MF_LAKE_CURSOR, 0, (NLEVELS + 9) * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(mf + MF_LAKE_CURSOR, 0, (MF_WORDS - MF_LAKE_CURSOR) * sizeof(uint64_t), c->stream));
   }
   const uint8_t *himg = cb ? hook_image(c, img, h, w, stride, opt->edge_correction) : nullptr;
   if (cb) c->host64.resize(n ? n : 1);
 
   rc = level_loop(c, lb, opt->max_water_level, merging, want_list, [&](uint32_t l) -> int {
     if (want_list) {
-      // offsets[l] = lake cursor before this level's records
-      HIP_TRY(c, hipMemcpyAsync(mf + MF_LAKE_OFFSETS + l, mf + MF_LAKE_CURSOR, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_CURSOR));
+      // offsets[l] = records before this level (offsets[0] = 0 from the memset); the kernel stores offsets[l + 1]
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_CURSOR,
+                            mf + MF_LAKE_COUNT + l, mf + MF_LAKE_OFFSETS + l + 1, (uint32_t *)(mf + MF_LAKE_DONE) + l));
     }
     if (cb) {
       if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
@@ -981,7 +982,6 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
 
   if (want_list) {
     const uint32_t levels = (uint32_t)opt->max_water_level + 1;
-    HIP_TRY(c, hipMemcpyAsync(mf + MF_LAKE_OFFSETS + levels, mf + MF_LAKE_CURSOR, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(offsets, mf + MF_LAKE_OFFSETS, (levels + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n_lakes = offsets[levels];

@@ -259,25 +259,38 @@ hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint3
   return hipGetLastError();
 }
 
-// lib.rs:628-635 sparsely: one (colour, area) record per lake with area > 0
+// lib.rs:628-635 sparsely: one (colour, area) record per lake with area > 0.  Records of one level are
+// contiguous: a record's position is `*total` (records of the earlier levels; nobody writes it while the level's
+// workgroups are busy) plus a ticket from this level's own counter.  The LAST workgroup to finish adds the
+// level's count to `*total` and stores it as the next level's offset -- no separate launch to snapshot a cursor.
 __global__ void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
-                             uint64_t *lakes, size_t cap, u64c *cursor) {
+                             uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done) {
+  const u64c base = *total;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;     // colour 0 = uncoloured
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n_colours; i += step) {
     const uint32_t area = size[i];
     if (parent[i] == (uint32_t)i && area) {
-      const u64c pos = atomicAdd(cursor, 1ull);
+      const u64c pos = base + atomicAdd(level_count, 1ull);
       if (pos < cap) { lakes[2 * pos] = (uint64_t)i; lakes[2 * pos + 1] = (uint64_t)area; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x - 1) {       // every other workgroup has read `*total` and taken its tickets
+      __threadfence();
+      const u64c sum = base + __hip_atomic_load(level_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *total = sum;
+      *next_offset = sum;
     }
   }
 }
 
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *cursor) {
-  if (n_colours <= 1) return hipSuccess;
-  const int blocks = (int)((n_colours + 255) / 256 < 4096 ? (n_colours + 255) / 256 : 4096);
-  k_emit_lakes<<<blocks, 256, 0, s>>>(parent, size, n_colours, lakes, cap, cursor);
+                      uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done) {
+  const int blocks = n_colours <= 1 ? 1 : (int)((n_colours + 255) / 256 < 4096 ? (n_colours + 255) / 256 : 4096);
+  k_emit_lakes<<<blocks, 256, 0, s>>>(parent, size, n_colours, lakes, cap, total, level_count, next_offset, done);
   return hipGetLastError();
 }
 

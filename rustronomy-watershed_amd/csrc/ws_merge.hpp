@@ -38,8 +38,10 @@ hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hoo
                       uint32_t *size);
 hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size);
 // appends (colour, area) of every root with area > 0 at lakes[*cursor ...); counts past cap too
+// total: records emitted by earlier levels; level_count / done: this level's ticket counter and finished-workgroup
+// counter (both zero on entry); next_offset receives total + this level's count
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *cursor);
+                      uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done);
 
 // final-only path: union every crossing edge of the whole image in one launch
 // final level only (coloured <=> label != 0); tile_min: union_image_tiles(h, w) words of scratch
