@@ -424,10 +424,10 @@ __device__ __forceinline__ bool image_corner(int y, int x, int H, int W) { retur
 //   k_tile_links   per tile: joins cmin with the cmin of the one-lake tile to the right / below;
 //                  k_tile_roots then replaces every tile's cmin by the root of its lake
 //   k_union_seeds  per SEED: colour i+1 joins the cmin of the tile its seed pixel lies in
-//   k_tile_edges   per tile edge pixel: the colours a tile can hold WITHOUT their seed came in over an
-//                  edge; one whose seed sits in another one-lake tile is joined already (by the two
-//                  lines above), the others join cmin here, as do the colours across the right /
-//                  bottom edge when the tile there is not a one-lake tile
+//   k_tile_edges   per tile edge pixel: a colour a tile holds WITHOUT its seed came in over an edge; if from a
+//                  one-lake tile, the two tiles are joined and that tile holds the colour already (induction
+//                  along the colour's region); if from a general tile, the colour joins cmin here, as do the
+//                  colours across the right / bottom edge when the tile there is general
 //   k_union_tiles  the general path (LDS union-find) for the tiles k_tile_scan turned down
 __global__ __launch_bounds__(256) void k_tile_scan(const uint32_t *__restrict__ labels, int H, int W, int tilesX, uint32_t *tile_min) {
   __shared__ uint32_t sWaveMin[4];
@@ -501,8 +501,7 @@ __global__ void k_union_seeds(const uint32_t *__restrict__ seeds_rc, size_t n_se
 }
 
 // wave = edge of the tile (0 bottom, 1 right, 2 top, 3 left), lane = position along it
-__global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ seeds_rc,
-                                                    int H, int W, int tilesX, int tilesY,
+__global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__ labels, int H, int W, int tilesX, int tilesY,
                                                     const uint32_t *__restrict__ tile_min, uint32_t *parent) {
   const uint32_t cmin = tile_min[blockIdx.x];
   if (cmin == 0u) return;
@@ -519,18 +518,22 @@ __global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__
   const uint32_t own_v = labels[(size_t)min(ey, H - 1) * W + min(ex, W - 1)];
   const uint32_t far_v = labels[(size_t)min(fy, H - 1) * W + min(fx, W - 1)];
   const uint32_t own = own_ok && !image_corner(ey, ex, H, W) ? own_v : 0u, far = far_ok ? far_v : 0u;
-  // the tile the seed of `own` lies in (colour c belongs to seed c - 1)
-  const uint2 src = reinterpret_cast<const uint2 *>(seeds_rc)[own ? own - 1u : 0u];
-  const uint32_t seed_tile_min = tile_min[(size_t)(src.x / UT) * tilesX + src.y / UT];
-  // one union per run of equal colours that want one
-  const uint32_t want_own = (own != 0u && own != cmin && seed_tile_min == 0u) ? own : 0u;
+  // the tile across this edge (none at the image border), and whether it is a general tile
+  const int nb = wave == 0 ? (tile_y + 1 < tilesY ? (int)blockIdx.x + tilesX : -1)
+               : wave == 1 ? (tile_x + 1 < tilesX ? (int)blockIdx.x + 1 : -1)
+               : wave == 2 ? (tile_y > 0 ? (int)blockIdx.x - tilesX : -1)
+                           : (tile_x > 0 ? (int)blockIdx.x - 1 : -1);
+  const uint32_t nb_min = nb >= 0 ? tile_min[nb] : 1u;
+  // own colours on an edge that faces a general tile join cmin: a colour whose seed lies elsewhere reached this
+  // tile over one of its edges, from a one-lake tile (joined with this one by k_tile_links, and holding the
+  // colour already, by induction along the colour's region) or from a general one -- this case.  One union per
+  // run of equal colours.
+  const uint32_t want_own = (own != 0u && own != cmin && nb_min == 0u) ? own : 0u;
   const uint32_t want_own_prev = __shfl_up(want_own, 1, 64);
   if (want_own != 0u && (lane == 0 || want_own != want_own_prev)) uf_union(parent, want_own, cmin);
-  // across the right / bottom edge: only when the tile there is not a one-lake tile (else k_tile_links joined the two)
-  const int nb = wave == 0 ? (tile_y + 1 < tilesY ? (int)blockIdx.x + tilesX : -1) : (tile_x + 1 < tilesX ? (int)blockIdx.x + 1 : -1);
-  const uint32_t nb_min = (wave < 2 && nb >= 0) ? tile_min[nb] : 1u;
+  // colours across the right / bottom edge, when the tile there is general (its own kernel only looks right and down)
   const bool pair_ok = own != 0u && far != 0u && (interior(ey, ex, H, W) || interior(fy, fx, H, W));
-  const uint32_t want_far = (pair_ok && nb_min == 0u && far != cmin) ? far : 0u;
+  const uint32_t want_far = (wave < 2 && pair_ok && nb_min == 0u && far != cmin) ? far : 0u;
   const uint32_t want_far_prev = __shfl_up(want_far, 1, 64);
   if (want_far != 0u && (lane == 0 || want_far != want_far_prev)) uf_union(parent, want_far, cmin);
 }
@@ -551,7 +554,7 @@ hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *se
     const int blocks = (int)std::min<size_t>((n_seeds + 255) / 256, 16384);
     k_union_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n_seeds, h, w, tx, tile_min, parent);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    k_tile_edges<<<tx * ty, 256, 0, s>>>(labels, seeds_rc, h, w, tx, ty, tile_min, parent);
+    k_tile_edges<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, ty, tile_min, parent);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   k_union_tiles<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, parent, tile_min);

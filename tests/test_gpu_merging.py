@@ -206,3 +206,61 @@ def test_merge_final_labels_full_level_border_and_corner_seeds(pkg, shape, edge)
     torch.cuda.synchronize()
     want = ol.merge_arrival(himg, hseeds, edge=edge)
     assert (got.cpu().numpy().view(np.uint32) == want).all()
+
+
+def test_merge_final_colour_enters_one_lake_tile_through_a_general_tile(pkg):
+    # tiles are 64 wide: tile 0 and tile 2 flood completely (one-lake tiles), tile 1 is a wall with a one-pixel
+    # corridor (a general tile).  Colour 2 (seeded in tile 0) reaches tile 2 only through the corridor, as a
+    # same-colour crossing pair, and meets colour 1 (seeded in tile 2) inside tile 2: one lake, id 1.
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    for h, w, wall in ((64, 192, (64, 128)), (60, 256, (64, 192)), (64, 320, (128, 192))):      # one tile row: no detour through a tile below
+        himg = np.full((h, w), 7, np.uint8)
+        himg[:, wall[0]:wall[1]] = 255
+        himg[30, wall[0]:wall[1]] = 7                                   # the corridor
+        himg[6:15, wall[1] + 16:wall[1] + 25] = 100                      # colour 1 sits in a pocket that floods late:
+        hseeds = np.array([[10, wall[1] + 20], [30, 10]], np.uint64)     # colour 2 (seeded before the wall) fills tile 2 first
+        img = torch.from_numpy(himg).to(eng.device)
+        seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(eng.device).contiguous()
+        got = eng.merge(img, seeds).cpu().numpy().view(np.uint32)
+        want = ol.merge_arrival(himg, hseeds)
+        assert (got == want).all(), (h, w)
+        assert set(np.unique(want)) == {0, 1}
+
+
+def test_merge_final_random_mazes_of_open_and_walled_tiles(pkg):
+    # mixtures of one-lake tiles (fully flooded 64x64 blocks) and general tiles (walls with corridors, pockets that
+    # flood late), few seeds in random order: every way a colour can reach a tile without its seed
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    rng = np.random.default_rng(int(__import__("os").environ.get("WS_TEST_SEED_OFFSET", "0")) + 4242)
+    for case in range(40):
+        ty, tx = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+        h, w = ty * 64 - int(rng.integers(0, 5)), tx * 64 - int(rng.integers(0, 5))
+        himg = np.full((h, w), 9, np.uint8)
+        for by in range(ty):
+            for bx in range(tx):
+                kind = rng.integers(0, 4)
+                y0, x0, y1, x1 = by * 64, bx * 64, min(by * 64 + 64, h), min(bx * 64 + 64, w)
+                if kind == 0:                                             # walled tile with a few corridors
+                    himg[y0:y1, x0:x1] = 255
+                    for _ in range(int(rng.integers(1, 4))):
+                        if rng.integers(0, 2):
+                            himg[int(rng.integers(y0, y1)), x0:x1] = 9
+                        else:
+                            himg[y0:y1, int(rng.integers(x0, x1))] = 9
+                elif kind == 1:                                           # open tile with late-flooding pockets
+                    for _ in range(int(rng.integers(1, 4))):
+                        py, px = int(rng.integers(y0, y1)), int(rng.integers(x0, x1))
+                        himg[py:py + 9, px:px + 9] = int(rng.integers(60, 250))
+        n_seeds = int(rng.integers(1, 9))
+        hseeds = np.stack([rng.integers(0, h, n_seeds), rng.integers(0, w, n_seeds)], axis=1).astype(np.uint64)
+        img = torch.from_numpy(himg).to(eng.device)
+        seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(eng.device).contiguous()
+        got = eng.merge(img, seeds).cpu().numpy().view(np.uint32)
+        want = ol.merge_arrival(himg, hseeds)
+        assert (got == want).all(), (case, h, w, n_seeds)
