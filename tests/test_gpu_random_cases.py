@@ -81,3 +81,42 @@ def test_random_medium_cases_seed_forms_and_merging():
         if case % 2 == 0:
             got = pkg.TransformBuilder.new().set_max_water_lvl(max_level).build_merging().transform_final(img, seeds)
             assert (got == ol.merge_arrival(img, seeds, max_level=max_level)).all(), ("merge", case, h, w, kind, form, max_level)
+
+
+def test_random_mazes_long_range_segmenting():
+    """Walls (NEVER_FILL) with random corridors, plateaus and ramps at the scale of the relaxation tiles (256 x 32):
+    floods that wind through many tiles, hundreds of rings per level, dozens to hundreds of passes -- the alternating
+    grids, the quadrant flags, the round cap of pass 0 and the row / column scans of the late passes."""
+    ge.build_hip()
+    pkg = ge.load_package()
+    rng = np.random.default_rng(1234 + int(os.environ.get("WS_TEST_SEED_OFFSET", "0")))
+    most_passes = 0
+    for case in range(16):
+        h = int(rng.integers(40, 300))
+        w = int(rng.integers(60, 330)) * 4 if case % 3 else int(rng.integers(200, 1300))
+        img = np.full((h, w), 255, np.uint8)
+        # corridors: random horizontal and vertical slits of random value through the wall
+        for _ in range(int(rng.integers(6, 40))):
+            v = int(rng.choice([3, 3, 3, 40, 120, 200]))
+            if rng.integers(0, 2):
+                y = int(rng.integers(1, h - 1)); x0, x1 = sorted(rng.integers(1, w - 1, 2))
+                img[y, x0:x1 + 1] = np.minimum(img[y, x0:x1 + 1], v)
+            else:
+                x = int(rng.integers(1, w - 1)); y0, y1 = sorted(rng.integers(1, h - 1, 2))
+                img[y0:y1 + 1, x] = np.minimum(img[y0:y1 + 1, x], v)
+        # a few open rooms (plateaus / ramps)
+        for _ in range(int(rng.integers(1, 5))):
+            y0, x0 = int(rng.integers(1, h - 8)), int(rng.integers(1, w - 8))
+            hh, ww = int(rng.integers(4, 60)), int(rng.integers(4, 300))
+            room = img[y0:y0 + hh, x0:x0 + ww]
+            ramp = ((np.arange(room.shape[1])[None, :] * int(rng.integers(0, 3))) // 4 + int(rng.integers(0, 200))) % 254
+            room[:] = np.minimum(room, np.broadcast_to(ramp, room.shape).astype(np.uint8))
+        open_px = np.argwhere(img < 255)
+        n_seeds = int(rng.integers(1, 6))
+        seeds = open_px[rng.choice(len(open_px), size=min(n_seeds, len(open_px)), replace=False)].astype(np.uint64)
+        ws = pkg.TransformBuilder.new().set_engine(pkg.ENGINE_FUSED).build_segmenting()
+        got = ws.transform(img, seeds)
+        want = ol.segment_arrival(img, seeds)
+        assert got.shape == want.shape and (got == want).all(), ("maze", case, h, w, n_seeds)
+        most_passes = max(most_passes, ws._ctx().stats()["relax_passes"])
+    assert most_passes >= 12, most_passes            # the late-pass kernel variants did run
