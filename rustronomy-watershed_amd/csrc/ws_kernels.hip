@@ -622,7 +622,7 @@ constexpr uint32_t RL_HALO = 0x4000u;           // pointer flag: ... namely a ha
 static_assert(RL_ROWS * RL_P <= (int)RL_HALO, "cell indices must stay below the flag bits");
 
 // TABLES: the seeds were never painted; their colours come from the side tables of a strictly
-// increasing seed list (k_paint_sorted<true>) and every pixel of the plane is written here.
+// increasing seed list (k_seed_tables) and every pixel of the plane is written here.
 template <bool TABLES>
 __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
