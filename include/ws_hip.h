@@ -188,7 +188,10 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out_labels);
 /* ---- device-resident entry points (inputs and outputs stay in HBM) ------------------- */
 
 /* d_img: device u8 plane; d_seeds_rc: device (row, col) pairs as uint32_t[2];
- * d_labels: device uint32_t plane of the (padded, if edge correction) shape. */
+ * d_labels: device uint32_t plane of the (padded, if edge correction) shape.
+ * Any seed list is accepted (duplicates: the later entry wins, lib.rs:1672-1677).  A list in strictly
+ * increasing row-major order -- what ws_find_local_minima(_device) returns -- takes a faster path; the
+ * engine checks the order on the device, nothing has to be declared. */
 int ws_find_local_minima_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w,
                                 size_t row_stride, uint32_t *d_out_rc, size_t cap,
                                 size_t *n_found);
