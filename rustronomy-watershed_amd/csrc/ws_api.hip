@@ -855,6 +855,7 @@ constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // NLEVELS u32 counter
 constexpr int MF_LAKE_COUNT = 6 * NLEVELS + 16;           // NLEVELS u64 per-level record counters
 constexpr int MF_LAKE_DONE = 7 * NLEVELS + 16;            // NLEVELS u32 finished-workgroup counters
 constexpr int MF_WORDS = 8 * NLEVELS + 24;
+constexpr uint32_t LIST_GROUP = 16;                       // levels per host copy of lake records (16 groups: kern_ev has 64)
 
 struct LevelBuckets {
   std::vector<uint64_t> off_px, off_ed;    // NLEVELS + 1 prefix sums
@@ -968,6 +969,9 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
       // offsets[l] = records before this level (offsets[0] = 0 from the memset); the kernel stores offsets[l + 1]
       HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_CURSOR,
                             mf + MF_LAKE_COUNT + l, mf + MF_LAKE_OFFSETS + l + 1, (uint32_t *)(mf + MF_LAKE_DONE) + l));
+      // every LIST_GROUP levels (and after the last): a marker, so that the records of finished levels can travel to
+      // the host while later levels are still being computed
+      if ((l + 1) % LIST_GROUP == 0 || l == opt->max_water_level) HIP_TRY(c, hipEventRecord(c->kern_ev[l / LIST_GROUP], c->stream));
     }
     if (cb) {
       if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
@@ -981,12 +985,24 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   if (rc) return rc;
 
   if (want_list) {
+    // All levels are queued.  Group by group: wait for the group's marker, read its offsets, copy its records
+    // (155 MB at 1024^2: as long over PCIe as the levels take to compute, so the two are overlapped).
     const uint32_t levels = (uint32_t)opt->max_water_level + 1;
-    HIP_TRY(c, hipMemcpyAsync(offsets, mf + MF_LAKE_OFFSETS, (levels + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    offsets[0] = 0;
+    size_t copied = 0;
+    for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
+      const uint32_t g1 = std::min(g0 + LIST_GROUP, levels);
+      HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g0 / LIST_GROUP], 0));
+      HIP_TRY(c, hipMemcpyAsync(offsets + g0 + 1, mf + MF_LAKE_OFFSETS + g0 + 1, (g1 - g0) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+      HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      const size_t end = std::min<size_t>(offsets[g1], cap);
+      if (end > copied) {
+        HIP_TRY(c, hipMemcpyAsync(lakes + copied, (const ws_lake *)c->lakes.p + copied, (end - copied) * sizeof(ws_lake), hipMemcpyDeviceToHost, c->copy_stream));
+        copied = end;
+      }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     *n_lakes = offsets[levels];
-    const size_t got = std::min<size_t>(*n_lakes, cap);
-    if (got) HIP_TRY(c, hipMemcpyAsync(lakes, c->lakes.p, got * sizeof(ws_lake), hipMemcpyDeviceToHost, c->stream));
     for (uint32_t l = 0; l < levels; ++l) uncoloured[l] = n - lb.off_px[l + 1];                // index 0 of lib.rs:630's vector
   }
   if (out_labels && n) {
