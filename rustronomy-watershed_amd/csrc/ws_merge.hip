@@ -507,6 +507,14 @@ __global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__
   if (cmin == 0u) return;
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the tile across this wave's edge (none at the image border).  Only a GENERAL tile there gives this wave
+  // anything to do -- checked before a single pixel is loaded: a tile edge is one pixel per row, a cache line
+  // fetched for each (the kernel moved 400 MB to look at 16 MB of pixels and find, on an ordinary field, nothing).
+  const int nb = wave == 0 ? (tile_y + 1 < tilesY ? (int)blockIdx.x + tilesX : -1)
+               : wave == 1 ? (tile_x + 1 < tilesX ? (int)blockIdx.x + 1 : -1)
+               : wave == 2 ? (tile_y > 0 ? (int)blockIdx.x - tilesX : -1)
+                           : (tile_x > 0 ? (int)blockIdx.x - 1 : -1);
+  if (nb < 0 || tile_min[nb] != 0u) return;
   const int x0 = tile_x * UT, y0 = tile_y * UT;
   const int ylast = min(y0 + UT, H) - 1, xlast = min(x0 + UT, W) - 1;       // the tile's last row / column inside the plane
   const int ey = wave == 0 ? ylast : (wave == 2 ? y0 : y0 + lane);
@@ -518,22 +526,15 @@ __global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__
   const uint32_t own_v = labels[(size_t)min(ey, H - 1) * W + min(ex, W - 1)];
   const uint32_t far_v = labels[(size_t)min(fy, H - 1) * W + min(fx, W - 1)];
   const uint32_t own = own_ok && !image_corner(ey, ex, H, W) ? own_v : 0u, far = far_ok ? far_v : 0u;
-  // the tile across this edge (none at the image border), and whether it is a general tile
-  const int nb = wave == 0 ? (tile_y + 1 < tilesY ? (int)blockIdx.x + tilesX : -1)
-               : wave == 1 ? (tile_x + 1 < tilesX ? (int)blockIdx.x + 1 : -1)
-               : wave == 2 ? (tile_y > 0 ? (int)blockIdx.x - tilesX : -1)
-                           : (tile_x > 0 ? (int)blockIdx.x - 1 : -1);
-  const uint32_t nb_min = nb >= 0 ? tile_min[nb] : 1u;
-  // own colours on an edge that faces a general tile join cmin: a colour whose seed lies elsewhere reached this
-  // tile over one of its edges, from a one-lake tile (joined with this one by k_tile_links, and holding the
-  // colour already, by induction along the colour's region) or from a general one -- this case.  One union per
-  // run of equal colours.
-  const uint32_t want_own = (own != 0u && own != cmin && nb_min == 0u) ? own : 0u;
+  // own colours on this edge join cmin: a colour whose seed lies elsewhere reached this tile over one of its
+  // edges, from a one-lake tile (joined with this one by k_tile_links, and holding the colour already, by
+  // induction along the colour's region) or from a general one -- this case.  One union per run of equal colours.
+  const uint32_t want_own = (own != 0u && own != cmin) ? own : 0u;
   const uint32_t want_own_prev = __shfl_up(want_own, 1, 64);
   if (want_own != 0u && (lane == 0 || want_own != want_own_prev)) uf_union(parent, want_own, cmin);
-  // colours across the right / bottom edge, when the tile there is general (its own kernel only looks right and down)
+  // colours across the right / bottom edge (the general tile's own kernel only looks right and down)
   const bool pair_ok = own != 0u && far != 0u && (interior(ey, ex, H, W) || interior(fy, fx, H, W));
-  const uint32_t want_far = (wave < 2 && pair_ok && nb_min == 0u && far != cmin) ? far : 0u;
+  const uint32_t want_far = (wave < 2 && pair_ok && far != cmin) ? far : 0u;
   const uint32_t want_far_prev = __shfl_up(want_far, 1, 64);
   if (want_far != 0u && (lane == 0 || want_far != want_far_prev)) uf_union(parent, want_far, cmin);
 }
