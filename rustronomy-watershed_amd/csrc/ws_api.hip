@@ -60,6 +60,8 @@ struct ws_ctx {
   bool have_keys = false;
   bool misc_clean = false;      // the error words of the flag block (FLAG_NERR of them) are known to be zero
   bool expect_sorted = true;    // the last seed list was strictly increasing: try the side-table form first
+  uint32_t *tile_min_out = nullptr;   // merging, final labels: run_fused lets the resolve kernel classify the 64x64 tiles into here
+  bool tile_min_filled = false;
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
 };
 
@@ -301,7 +303,9 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   if (n < 0x80000000ull) {
     Span sp(c, KC_RESOLVE);
     if ((rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base));
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
+                                  c->tile_min_out));
+    c->tile_min_filled = c->tile_min_out != nullptr;
     c->stats.resolve_passes = 2;
   } else {
     rc = pass_loop(c, flags, ntiles, &c->stats.resolve_passes, [&](uint32_t pass) {
@@ -1059,13 +1063,18 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
     src_stride = pw;
   }
   uint32_t *seg = (uint32_t *)c->labels.p;
-  if ((rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, seg))) return rc;
+  if ((rc = ensure(c, c->counts, std::max<size_t>(union_image_tiles((int)ph, (int)pw), 1) * sizeof(uint32_t)))) return rc;
+  c->tile_min_out = (uint32_t *)c->counts.p;      // the resolve kernel classifies the tiles while it has them in registers
+  c->tile_min_filled = false;
+  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, seg);
+  c->tile_min_out = nullptr;
+  if (rc) return rc;
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
   {
     Span sp(c, KC_OTHER);
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
-    if ((rc = ensure(c, c->counts, std::max<size_t>(union_image_tiles((int)ph, (int)pw), 1) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, union_image(c->stream, seg, d_seeds_rc, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p));
+    HIP_TRY(c, union_image(c->stream, seg, d_seeds_rc, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
+                           c->tile_min_filled));
     HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n));
   }
   c->stats.merge_levels = 1;

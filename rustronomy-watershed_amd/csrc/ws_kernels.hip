@@ -623,12 +623,17 @@ static_assert(RL_ROWS * RL_P <= (int)RL_HALO, "cell indices must stay below the 
 
 // TABLES: the seeds were never painted; their colours come from the side tables of a strictly
 // increasing seed list (k_seed_tables) and every pixel of the plane is written here.
-template <bool TABLES>
+// MERGE: the merging transform's final-labels path wants to know, per 64 x 64 tile, whether the tile is one lake
+// (every image-interior pixel coloured) and a colour to stand for it -- both are lying around here: tile_min[tile] =
+// a colour of the tile that is not a reference (0: not one lake; RL_TILE_UNDECIDED: one lake, but every pixel's
+// chain leaves the tile, k_tile_scan looks at the finished labels).  Saves a 268 MB pass over the label plane.
+constexpr uint32_t RL_TILE_UNDECIDED = 0xFFFFFFFFu;
+template <bool TABLES, bool MERGE>
 __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
-                                                            const uint32_t *__restrict__ word_base) {
+                                                            const uint32_t *__restrict__ word_base, uint32_t *tile_min) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   const uint32_t tile = xcd_span_index(blockIdx.x, gridDim.x);
@@ -840,6 +845,49 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       }
     }
   }
+  if (MERGE) {
+    // min and max of (label - 1) over the patch: an uncoloured pixel (0) wraps to the top, a reference lies at or
+    // above REF_BIT - 1; so max == ~0 says "a hole", min < REF_BIT - 1 is a colour that needs no chase
+    __shared__ uint32_t sTileLo[NTHREADS / 64], sTileHi[NTHREADS / 64], sTileAny[NTHREADS / 64];
+    const bool border_tile = x0 == 0 || y0 == 0 || x0 + TS >= W || y0 + TS >= H;      // uniform
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    bool any_interior = !border_tile;
+    if (!border_tile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t t = out[r][c] - 1u; lo = min(lo, t); hi = max(hi, t); }
+    } else {
+      // image-border pixels never flood (lib.rs:1693-1697 pads with NEVER_FILL): only interior pixels decide "one lake";
+      // a corner pixel touches no interior pixel, its colour never merges and must not stand for the tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gy = gy0 + r, gx = gx0 + c;
+          const bool in_plane = gy < H && gx < W;
+          const bool inter = gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1;
+          const bool corner = (gy == 0 || gy == H - 1) && (gx == 0 || gx == W - 1);
+          const uint32_t t = out[r][c] - 1u;
+          if (in_plane && !corner) lo = min(lo, t);
+          if (inter) { hi = max(hi, t); any_interior = true; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
+      hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
+    }
+    const bool wave_any = __ballot(any_interior) != 0ull;
+    if (lane == 0) { sTileLo[wave] = lo; sTileHi[wave] = hi; sTileAny[wave] = wave_any ? 1u : 0u; }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t l = sTileLo[0], h2 = sTileHi[0], a = sTileAny[0];
+#pragma unroll
+      for (int k = 1; k < NTHREADS / 64; ++k) { l = min(l, sTileLo[k]); h2 = max(h2, sTileHi[k]); a |= sTileAny[k]; }
+      const bool one_lake = h2 != 0xFFFFFFFFu && a != 0u;
+      tile_min[tile] = !one_lake ? 0u : (l < REF_BIT - 1u ? l + 1u : RL_TILE_UNDECIDED);
+    }
+  }
   WS_STAMP(4);
   // work list of the reference pixels for k_resolve_chase: every WAVE owns a fixed region of the list
   // (64 lanes x 16 pixels) and a count word -- no reservation atomic, no barrier, no cross-wave offsets
@@ -888,16 +936,20 @@ size_t resolve_ref_capacity(int h, int w) {
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
-                              uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base) {
+                              uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
-  if (seed_mask)
-    k_resolve_local<true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base);
+  if (seed_mask && tile_min)
+    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min);
+  else if (seed_mask)
+    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr);
+  else if (tile_min)
+    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min);
   else
-    k_resolve_local<false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr);
+    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);

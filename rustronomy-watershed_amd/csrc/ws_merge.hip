@@ -429,8 +429,11 @@ __device__ __forceinline__ bool image_corner(int y, int x, int H, int W) { retur
 //                  along the colour's region); if from a general tile, the colour joins cmin here, as do the
 //                  colours across the right / bottom edge when the tile there is general
 //   k_union_tiles  the general path (LDS union-find) for the tiles k_tile_scan turned down
-__global__ __launch_bounds__(256) void k_tile_scan(const uint32_t *__restrict__ labels, int H, int W, int tilesX, uint32_t *tile_min) {
+// preclassified: the resolve kernel has filled tile_min already; only its "undecided" tiles are looked at
+__global__ __launch_bounds__(256) void k_tile_scan(const uint32_t *__restrict__ labels, int H, int W, int tilesX, uint32_t *tile_min,
+                                                   int preclassified) {
   __shared__ uint32_t sWaveMin[4];
+  if (preclassified && tile_min[blockIdx.x] != 0xFFFFFFFFu) return;
   const int tile_x = blockIdx.x % tilesX, tile_y = blockIdx.x / tilesX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = tile_x * UT, y0 = tile_y * UT;
@@ -541,11 +544,11 @@ __global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__
 
 // tile_min: union_image_tiles(h, w) words of scratch
 hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *seeds_rc, size_t n_seeds, int h, int w,
-                       uint32_t *parent, uint32_t *tile_min) {
+                       uint32_t *parent, uint32_t *tile_min, bool preclassified) {
   if (h == 0 || w == 0) return hipSuccess;
   const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
   hipError_t e;
-  k_tile_scan<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, tile_min);
+  k_tile_scan<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, tile_min, preclassified ? 1 : 0);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   k_tile_links<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx, ty, parent);
   if ((e = hipGetLastError()) != hipSuccess) return e;
