@@ -6,9 +6,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # a transform starts at the seed scatter
-starts = [i for i, n in enumerate(names) if "k_paint_sorted" in n]
+starts = [i for i, n in enumerate(names) if "k_paint_sorted" in n or "k_seed_tables" in n]
 if not starts:
-    sys.exit("no k_paint_sorted launch in trace")
+    sys.exit("no seed kernel launch in trace")
 lo = starts[-1]
 t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:]:
