@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -199,9 +200,14 @@ int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *
 // Flag slots live in a ring of COUNTER_RING passes (pass q clears the slot of pass q + 1): two groups
 // in flight must stay below it.
 constexpr uint32_t PASS_GROUP_MAX = 16;
+// `speculate(last_pass)` (optional) is called once, right after the first lookahead group is queued: work that is only
+// valid at the fixpoint may be queued there behind pass `last_pass`, gated on the device by that pass's convergence slot
+// (edge_slot()); `*converged_at` = the first pass found to have changed nothing, so the caller can tell whether the gate
+// was open (converged_at <= last_pass: a pass after a clean pass is clean).
+inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass);
 template <class F>
 int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out, F launch, bool zeroed = false,
-              uint32_t first_group = 2) {
+              uint32_t first_group = 2, const std::function<int(uint32_t)> &speculate = nullptr, uint32_t *converged_at = nullptr) {
   static_assert(2 * PASS_GROUP_MAX < COUNTER_RING, "groups in flight must fit the flag ring");
   if (first_group > PASS_GROUP_MAX) first_group = PASS_GROUP_MAX;
   if (!zeroed) {        // the tile-edge stamps and the convergence ring start at zero
@@ -232,12 +238,17 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   int rc;
   if ((rc = launch_group(first_group, &done))) return rc;
   uint32_t size = 1;          // the first lookahead group: one pass is enough to keep the stream busy while the host reads
+  bool first = true;
   for (;;) {
     if ((rc = launch_group(size, &ahead))) return rc;
+    if (first && speculate && (rc = speculate(launched - 1))) return rc;
+    first = false;
     HIP_TRY(c, hipEventSynchronize(c->ring_ev[done.ev]));
     bool converged = false;
-    for (uint32_t p = done.lo; p < done.hi && !converged; ++p)
+    for (uint32_t p = done.lo; p < done.hi && !converged; ++p) {
       converged = !slot_nonzero(&c->pinned[FLAG_EDGE + (p % COUNTER_RING) * FLAG_SLOT]);
+      if (converged && converged_at) *converged_at = p;
+    }
     if (converged) break;
     done = ahead;
     size = std::min(size * 2, PASS_GROUP_MAX);
@@ -246,6 +257,10 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring_ev[ahead.ev], 0));
   *passes_out = launched;
   return WS_OK;
+}
+
+inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass) {
+  return d_flags + FLAG_EDGE + (size_t)(pass % COUNTER_RING) * FLAG_SLOT;
 }
 
 // Seeds reach the kernels in one of two forms.  TABLES: a strictly increasing list (what
@@ -291,20 +306,37 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   if (n == 0) return WS_OK;
 
   const PassFlags pf = make_pf(c);
+  // The label resolve is queued speculatively behind the first lookahead pass, gated on the device by that pass's
+  // convergence slot: when the host then reads that the flood was already at its fixpoint (the bench field: always),
+  // the labels are being written while it reads, instead of the GPU idling through the round trip.
+  const bool two_launch = n < 0x80000000ull;
+  static const bool no_speculation = getenv("WS_NO_SPECULATION") != nullptr;      // A/B knob for tools/
+  if (two_launch && (rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
+  auto resolve = [&](const uint32_t *gate) -> int {
+    Span sp(c, KC_RESOLVE);
+    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
+                                  c->tile_min_out, gate));
+    return WS_OK;
+  };
+  uint32_t speculated_after = 0xFFFFFFFFu, converged_at = 0xFFFFFFFFu;
+  std::function<int(uint32_t)> speculate = nullptr;
+  if (two_launch && !no_speculation)
+    speculate = [&](uint32_t last_pass) -> int {
+      speculated_after = last_pass;
+      return resolve(edge_slot(flags, last_pass));
+    };
   rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
                       tables ? seed_mask : d_labels, tables);
-  }, true, 5);
+  }, true, 5, speculate, &converged_at);
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
 
   // no host round trip here: the error words are read once, after the resolve launches are queued
-  if (n < 0x80000000ull) {
-    Span sp(c, KC_RESOLVE);
-    if ((rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
-                                  c->tile_min_out));
+  if (two_launch) {
+    const bool already = speculated_after != 0xFFFFFFFFu && converged_at <= speculated_after;     // the gate was open
+    if (!already && (rc = resolve(nullptr))) return rc;
     c->tile_min_filled = c->tile_min_out != nullptr;
     c->stats.resolve_passes = 2;
   } else {

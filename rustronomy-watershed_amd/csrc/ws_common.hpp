@@ -85,7 +85,8 @@ size_t resolve_ref_capacity(int h, int w);
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
                               uint32_t max_rounds = 0xFFFFFFFFu,
                               const uint32_t *seed_mask = nullptr, const uint32_t *word_base = nullptr,    // seed_tables() form
-                              uint32_t *tile_min = nullptr);      // merging: per 64x64 tile, one lake? + a colour of it (ws_merge.hpp)
+                              uint32_t *tile_min = nullptr,       // merging: per 64x64 tile, one lake? + a colour of it (ws_merge.hpp)
+                              const uint32_t *gate = nullptr);    // speculative launch: a pass's convergence slot; both kernels leave if it is set
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

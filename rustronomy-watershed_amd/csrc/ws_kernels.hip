@@ -633,9 +633,13 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
                                                             int H, int W, int tilesX, uint32_t *ref_count,
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
-                                                            const uint32_t *__restrict__ word_base, uint32_t *tile_min) {
+                                                            const uint32_t *__restrict__ word_base, uint32_t *tile_min,
+                                                            const uint32_t *__restrict__ gate) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
+  // Speculative launch (ws_api.hip): queued behind a relaxation pass before the host knows whether that pass still
+  // changed anything.  `gate` is the pass's striped convergence slot: any word set -> not a fixpoint yet, leave.
+  if (gate && __builtin_amdgcn_ballot_w64(gate[(threadIdx.x & 63) * STRIPE_STRIDE] != 0u) != 0ull) return;
   const uint32_t tile = xcd_span_index(blockIdx.x, gridDim.x);
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int tid = threadIdx.x;
@@ -913,8 +917,10 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 // smaller stamp, so chains end at a seed; a racing reader sees either the reference or what it
 // resolves to.
 __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
-                                const uint32_t *__restrict__ ref_list, size_t nregions, size_t n) {
+                                const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
+                                const uint32_t *__restrict__ gate) {
   const int lane = threadIdx.x & 63;
+  if (gate && __builtin_amdgcn_ballot_w64(gate[lane * STRIPE_STRIDE] != 0u) != 0ull) return;      // see k_resolve_local
   const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t region = wave0; region < nregions; region += nwaves) {
     const uint32_t count = ref_count[region];
@@ -936,24 +942,25 @@ size_t resolve_ref_capacity(int h, int w) {
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
-                              uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min) {
+                              uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min,
+                              const uint32_t *gate) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
   if (seed_mask && tile_min)
-    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min);
+    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate);
   else if (seed_mask)
-    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr);
+    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate);
   else if (tile_min)
-    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min);
+    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate);
   else
-    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr);
+    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate);
   return hipGetLastError();
 }
 
