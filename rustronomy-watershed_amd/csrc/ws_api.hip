@@ -44,7 +44,7 @@ struct ws_ctx {
   std::string err;
   ws_stats stats{};
 
-  DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux;
+  DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux, seed_stack;
   DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
@@ -271,8 +271,11 @@ inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass) {
 // known on the device, so the choice is a prediction: the context tries TABLES while the previous
 // list was strictly increasing; a wrong guess is detected by the table builder itself
 // (FLAG_NONSTRICT), costs one wasted transform, and flips the prediction.
+// slice_h > 0: the plane is a stack of ph / slice_h independent slices (ws_segment_batch_device); d_seeds are then in
+// stacked coordinates and slice_first (device) holds every slice's first list index, so that colours restart per slice.
 int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
-                   const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted) {
+                   const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted,
+                   int slice_h = 0, const uint32_t *slice_first = nullptr) {
   const size_t n = (size_t)ph * pw;
   const size_t ntiles = (size_t)tiles_of(pw) * tiles_of(ph);
   const size_t nwords = (n + 31) / 32;
@@ -298,7 +301,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     // arrival-stamp plane is not touched: relaxation pass 0 derives it from the seeds.
     if (tables)
       HIP_TRY(c, seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
-                             relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
+                             relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw));
     else      // one pass over the label plane paints the seeds (colour i + 1, later duplicates win), zero elsewhere
       HIP_TRY(c, paint_labels(c->stream, d_seeds, n_seeds, ph, pw, d_labels, flags + FLAG_SEED_ERR, stamps,
                               relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
@@ -315,7 +318,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto resolve = [&](const uint32_t *gate) -> int {
     Span sp(c, KC_RESOLVE);
     HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
-                                  c->tile_min_out, gate));
+                                  c->tile_min_out, gate, slice_h));
     return WS_OK;
   };
   uint32_t speculated_after = 0xFFFFFFFFu, converged_at = 0xFFFFFFFFu;
@@ -328,7 +331,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables);
+                      tables ? seed_mask : d_labels, tables, slice_h);
   }, true, 5, speculate, &converged_at);
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
@@ -604,7 +607,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux,
+  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack,
                     &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -1057,6 +1060,60 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
 extern "C" {
 
 // Final canonical labels only: one union pass over the whole image, no level buckets.
+// A batch of equal-sized independent slices.  Fast path: the slices are stacked into ONE plane of S * h rows whose slice
+// border rows are walls (they are image-border rows of their slices: never flooded), the seed lists are moved to stacked
+// coordinates and the whole batch runs as a single transform -- one set of launches and one host round trip instead of
+// S of each (8 x 4096^2: 2.0 -> ~1.4 ms; 16 x 1024^2: 2.2 ms -> ~0.3 ms).  Needs strictly increasing seed lists (the
+// side-table form), w % 4 == 0, h * w % 128 == 0 and contiguous slices; anything else, and any error (so that the
+// failing slice can be named), takes the slice-by-slice loop.
+static int segment_batch_stacked(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, size_t h, size_t w, size_t stride,
+                                 const uint32_t *d_seeds_rc, const size_t *seed_offsets, const ws_options *opt,
+                                 uint32_t *d_labels, bool *done) {
+  *done = false;
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  static const bool off = getenv("WS_NO_BATCH_STACK") != nullptr || getenv("WS_NO_SEED_TABLES") != nullptr;      // A/B knobs for tools/
+  const size_t plane = ph * pw;
+  if (off || n_slices < 2 || pick_engine(opt) != WS_ENGINE_FUSED || !c->expect_sorted || (pw & 3) != 0 || plane == 0 ||
+      plane % 128 != 0 || plane >= 0x40000000ull || (!opt->edge_correction && stride != w))
+    return WS_OK;
+  if (seed_offsets[n_slices] - seed_offsets[0] >= 0xFFFFFFFFull) return WS_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t per_group = std::max<size_t>(1, (0x7FFFFFFFull / plane));      // the two-launch resolve indexes pixels with 31 bits
+  std::vector<uint32_t> first;
+  for (size_t k0 = 0; k0 < n_slices; k0 += per_group) {
+    const size_t g = std::min(per_group, n_slices - k0);
+    const size_t s0 = seed_offsets[k0], ns = seed_offsets[k0 + g] - s0;
+    if (ns == 0) return WS_OK;
+    stats_begin(c);
+    const uint8_t *src = d_cube + k0 * h * stride;
+    size_t src_stride = stride;
+    if (opt->edge_correction) {
+      if ((rc = ensure(c, c->img, g * plane))) return rc;
+      for (size_t k = 0; k < g; ++k)
+        HIP_TRY(c, pad_image(c->stream, d_cube + (k0 + k) * h * stride, stride, (int)h, (int)w, (uint8_t *)c->img.p + k * plane));
+      src = (const uint8_t *)c->img.p;
+      src_stride = pw;
+    }
+    first.resize(g + 1);
+    for (size_t k = 0; k <= g; ++k) first[k] = (uint32_t)(seed_offsets[k0 + k] - s0);
+    if ((rc = ensure(c, c->seed_stack, (ns * 2 + g + 1) * sizeof(uint32_t)))) return rc;
+    uint32_t *stacked = (uint32_t *)c->seed_stack.p, *d_first = stacked + ns * 2;
+    HIP_TRY(c, hipMemcpyAsync(d_first, first.data(), (g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, stack_seeds(c->stream, d_seeds_rc + 2 * s0, ns, d_first, g, (int)ph, (int)pw, stacked));
+    bool mispredicted = false;
+    rc = run_fused_form(c, src, src_stride, (int)(g * ph), (int)pw, opt->max_water_level, stacked, ns, d_labels + k0 * plane, true,
+                        &mispredicted, (int)ph, d_first);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // `first` is reused by the next group
+    if (rc != WS_OK || mispredicted) { c->err.clear(); return WS_OK; }      // the loop repeats the work and names the slice
+    c->have_keys = false;      // the stamps are those of a stack, not of an image
+    if ((rc = stats_end(c))) return rc;
+  }
+  *done = true;
+  return WS_OK;
+}
+
 int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, size_t h, size_t w, size_t stride,
                             size_t slice_stride, const uint32_t *d_seeds_rc, const size_t *seed_offsets,
                             const ws_options *opt, uint32_t *d_labels, size_t *failed_slice) {
@@ -1065,8 +1122,15 @@ int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, s
   if (n_slices && (!seed_offsets || !opt)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
   if (n_slices > 1 && slice_stride < h * stride) return fail(c, WS_ERR_BAD_ARG, "slice_stride < h * row_stride");
   const size_t e = opt && opt->edge_correction ? 2 : 0, plane = (h + e) * (w + e);
-  for (size_t k = 0; k < n_slices; ++k) {
+  for (size_t k = 0; k < n_slices; ++k)
     if (seed_offsets[k + 1] < seed_offsets[k]) return fail(c, WS_ERR_BAD_ARG, "seed_offsets must not decrease");
+  if (n_slices > 1 && slice_stride == h * stride && d_cube && d_seeds_rc && d_labels) {
+    bool done = false;
+    const int rc = segment_batch_stacked(c, d_cube, n_slices, h, w, stride, d_seeds_rc, seed_offsets, opt, d_labels, &done);
+    if (rc != WS_OK) return rc;
+    if (done) return WS_OK;
+  }
+  for (size_t k = 0; k < n_slices; ++k) {
     const int rc = ws_segment_device(c, d_cube + k * slice_stride, h, w, stride, d_seeds_rc + 2 * seed_offsets[k],
                                      seed_offsets[k + 1] - seed_offsets[k], opt, d_labels + k * plane);
     if (rc != WS_OK) { if (failed_slice) *failed_slice = k; return rc; }

@@ -63,7 +63,11 @@ hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t
 hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *labels,
                         uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
 hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
-                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
+                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
+                       const uint32_t *slice_first = nullptr, size_t slice_px = 0);     // stack of slices: colours restart in every slice
+// seeds of a stack of slices -> seeds of the stacked plane (row + slice * slice_h); slice_first: n_slices + 1 list offsets
+hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
+                       int slice_h, int pw, uint32_t *stacked_rc);
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);
@@ -73,7 +77,8 @@ size_t relax_tiles(int h, int w);
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels = nullptr,    // non-null: pass 0 derives the stamps from this label plane
-                      bool seed_bits = false);                  // ... which is one bit per pixel (seed_tables) instead
+                      bool seed_bits = false,                   // ... which is one bit per pixel (seed_tables) instead
+                      int slice_h = 0);                         // > 0: the plane is a stack of independent slices of this many rows
 
 // label resolve, iterative form (row blocks of a tiled field, planes >= 2^31 pixels): 64x64 tiles
 size_t resolve_tiles(int h, int w);
@@ -86,7 +91,8 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
                               uint32_t max_rounds = 0xFFFFFFFFu,
                               const uint32_t *seed_mask = nullptr, const uint32_t *word_base = nullptr,    // seed_tables() form
                               uint32_t *tile_min = nullptr,       // merging: per 64x64 tile, one lake? + a colour of it (ws_merge.hpp)
-                              const uint32_t *gate = nullptr);    // speculative launch: a pass's convergence slot; both kernels leave if it is set
+                              const uint32_t *gate = nullptr,     // speculative launch: a pass's convergence slot; both kernels leave if it is set
+                              int slice_h = 0);                   // > 0: stack of independent slices (see relax_pass)
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

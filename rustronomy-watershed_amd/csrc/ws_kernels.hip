@@ -285,7 +285,8 @@ constexpr int TAB_WORDS = 256;       // mask words per wave (8192 pixels): four 
 __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
                                                                  uint32_t *mask, uint32_t *word_base, size_t npx, size_t nchunk,
                                                                  uint32_t *flags,
-                                                                 uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+                                                                 uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
+                                                                 const uint32_t *__restrict__ slice_first, size_t slice_px) {
   __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][TAB_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
@@ -338,7 +339,9 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
     const uint32_t v = __shfl_up(incl, o, 64);
     if (lane >= o) incl += v;
   }
-  const uint32_t b0 = (uint32_t)lo + incl - cnt;
+  uint32_t b0 = (uint32_t)lo + incl - cnt;
+  // a stack of slices (slice_px % 128 == 0: a lane's four words lie in one slice): list indices count from the slice's first seed
+  if (slice_first) b0 -= slice_first[(p0 + 128ull * (unsigned)lane) / slice_px];
   const u32x4_z bases = u32x4_z{b0, b0 + c0, b0 + c0 + c1, b0 + c0 + c1 + c2};
   const size_t wi = (size_t)(p0 >> 5) + 4 * lane, nwords = (npx + 31) / 32;
   if (wi + 4 <= nwords && ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(word_base)) & 15u) == 0) {
@@ -383,13 +386,42 @@ hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int p
 // `mask` and `word_base` hold (ph * pw + 31) / 32 words each.  The caller reads err_flag[2] ("not strictly
 // increasing") back and, if it is raised, repeats the transform with paint_labels.
 hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
-                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+                       uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
+                       const uint32_t *slice_first, size_t slice_px) {
   const size_t npx = (size_t)ph * pw;
   const size_t per_wave = (size_t)TAB_WORDS * 32;
   const size_t nchunk = (npx + per_wave - 1) / per_wave;
   const size_t blocks = std::max<size_t>((nchunk + PAINT_WAVES - 1) / PAINT_WAVES, 1);
   k_seed_tables<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, mask, word_base, npx, nchunk, err_flag,
-                                                             zero_a, n_zero_a, zero_b, n_zero_b);
+                                                             zero_a, n_zero_a, zero_b, n_zero_b, slice_first, slice_px);
+  return hipGetLastError();
+}
+
+// Seed i of a batch belongs to the slice k with slice_first[k] <= i < slice_first[k + 1]; in the stacked plane it sits
+// k * slice_h rows further down.  A seed outside its own slice must not land in a neighbour: it becomes (~0, ~0), which
+// every seed kernel reports as out of bounds.
+__global__ void k_stack_seeds(const uint2 *__restrict__ seeds, size_t n, const uint32_t *__restrict__ slice_first, size_t n_slices,
+                              int slice_h, int pw, uint2 *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    size_t lo = 0, hi = n_slices;            // largest k with slice_first[k] <= i
+    while (hi - lo > 1) {
+      const size_t mid = (lo + hi) / 2;
+      if (slice_first[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint2 rc = seeds[i];
+    const bool ok = rc.x < (uint32_t)slice_h && rc.y < (uint32_t)pw;
+    out[i] = ok ? make_uint2(rc.x + (uint32_t)lo * (uint32_t)slice_h, rc.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  }
+}
+
+hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
+                       int slice_h, int pw, uint32_t *stacked_rc) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  k_stack_seeds<<<blocks, 256, 0, s>>>(reinterpret_cast<const uint2 *>(seeds_rc), n, slice_first, n_slices, slice_h, pw,
+                                       reinterpret_cast<uint2 *>(stacked_rc));
   return hipGetLastError();
 }
 
@@ -634,7 +666,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
                                                             const uint32_t *__restrict__ word_base, uint32_t *tile_min,
-                                                            const uint32_t *__restrict__ gate) {
+                                                            const uint32_t *__restrict__ gate, int SH) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   // Speculative launch (ws_api.hip): queued behind a relaxation pass before the host knows whether that pass still
@@ -722,9 +754,11 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
     // to ~75 instructions per pixel of exec-mask juggling and was the longest phase of the kernel.
     const uint32_t top_halo = pr == 0, bot_halo = pr == 15, left_halo = pc == 0, right_halo = pc == 15;
     uint32_t row_int[4], col_int[4];
+    const int ry0 = SH == H ? gy0 : gy0 % SH;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      row_int[i] = (uint32_t)(gy0 + i >= 1) & (uint32_t)(gy0 + i < H - 1);
+      const int ry = ry0 + i >= SH ? ry0 + i - SH : ry0 + i;       // row inside its slice (SH == H: one image)
+      row_int[i] = (uint32_t)(ry >= 1) & (uint32_t)(ry < SH - 1) & (uint32_t)(gy0 + i < H);
       col_int[i] = (uint32_t)(gx0 + i >= 1) & (uint32_t)(gx0 + i < W - 1);
     }
 #pragma unroll
@@ -943,20 +977,21 @@ size_t resolve_ref_capacity(int h, int w) {
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
                               uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min,
-                              const uint32_t *gate) {
+                              const uint32_t *gate, int slice_h) {
   const int tx = tiles_of(w), ty = tiles_of(h);
+  const int sh = slice_h > 0 ? slice_h : h;
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
   if (seed_mask && tile_min)
-    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate);
+    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh);
   else if (seed_mask)
-    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate);
+    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh);
   else if (tile_min)
-    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate);
+    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh);
   else
-    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate);
+    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);

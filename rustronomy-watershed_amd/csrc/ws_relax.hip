@@ -249,7 +249,9 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
-                                                      const uint32_t *__restrict__ seed_labels, int seed_bits) {
+                                                      const uint32_t *__restrict__ seed_labels, int seed_bits, int SH) {
+  // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
+  // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
   // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
   __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NW + 2][RX_TW];
@@ -393,10 +395,13 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     halo_row.x = halo_row.x ? 0u : KEY_INF; halo_row.y = halo_row.y ? 0u : KEY_INF;
     halo_row.z = halo_row.z ? 0u : KEY_INF; halo_row.w = halo_row.w ? 0u : KEY_INF;
   }
+  // row inside its slice: the four rows of a patch are all above the plane or all from row 0 on
+  const int ry0 = (SH == H || gyb < 0) ? gyb : gyb % SH;
 #pragma unroll
   for (int r = 0; r < RX_P; ++r) {
     const int gy = gyb + r;
-    const bool row_ok = gy >= 0 && gy < H, row_int = gy >= 1 && gy < H - 1;
+    const int ry = ry0 + r >= SH ? ry0 + r - SH : ry0 + r;
+    const bool row_ok = gy >= 0 && gy < H, row_int = ry >= 1 && ry < SH - 1 && gy < H;
 #pragma unroll
     for (int c = 0; c < RX_P; ++c) {
       const int gx = gx0 + c;
@@ -589,8 +594,9 @@ size_t relax_tiles(int h, int w) {
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels, bool seed_bits) {
+                      const uint32_t *seed_labels, bool seed_bits, int slice_h) {
   const int th = RX_NW * RX_P;
+  const int sh = slice_h > 0 ? slice_h : h;
   const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + th - 1) / th;     // grid anchored at (0, 0): even passes
   const int sx = ax + 1, sy = ay + 1;                                 // grid shifted by half a tile: odd passes
   const int shifted = (int)(pass & 1u);
@@ -616,16 +622,16 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from) {
     k_relax<RX_NW, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                prev, cur, pf, max_iters, sl, sb);
+                                                                prev, cur, pf, max_iters, sl, sb, sh);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
     if (pass < RX_SCAN_FROM_PASS)
       k_relax<RX_NW, true, false><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh);
     else
       k_relax<RX_NW, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh);
   }
   return hipGetLastError();
 }

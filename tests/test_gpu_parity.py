@@ -340,3 +340,68 @@ def test_segment_batch_of_independent_slices(pkg):
     got = eng.segment_batch(cube, allseeds, offs).cpu().numpy().view(np.uint32)
     for k in range(s):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+
+
+def _batch_case(s, h, w, first_seed):
+    """s slices, the local minima of each plus seeds on its first / last row and in a corner (border seeds keep their
+    colour but never flood: in a stacked batch they sit right next to the neighbouring slice)."""
+    himgs, hseeds = [], []
+    for k in range(s):
+        a = cases.field(h, w, first_seed + k) if k % 2 == 0 else cases.smooth_field(h, w, first_seed + k)
+        extra = np.array([[0, 0], [0, w // 2], [h - 1, 1], [h - 1, w - 1]], dtype=np.int64)
+        sd = np.unique(np.concatenate([ol.find_local_minima(a).astype(np.int64).reshape(-1, 2), extra]), axis=0)      # sorted row-major
+        himgs.append(a)
+        hseeds.append(sd)
+    return himgs, hseeds
+
+
+def _run_batch(eng, himgs, hseeds, edge=False):
+    import torch
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
+    cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
+    allseeds = torch.from_numpy(np.concatenate(hseeds).astype(np.int64).reshape(-1, 2)).to(torch.int32).to(eng.device).contiguous()
+    return eng.segment_batch(cube, allseeds, offs, edge=edge).cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("s,h,w,edge", [
+    (4, 40, 64, False),      # slices end inside relaxation tiles (32 rows) and resolve tiles (64 rows)
+    (3, 64, 64, False),      # slices = resolve tiles
+    (6, 30, 128, False),
+    (9, 8, 16, False),       # many thin slices inside one tile
+    (3, 62, 62, True),       # edge correction: padded slices of 64 x 64
+    (2, 33, 36, False),      # 33 * 36 % 128 != 0: the slice-by-slice loop
+    (3, 40, 66, False),      # w % 4 != 0: the loop
+])
+def test_segment_batch_stacked_forms(pkg, s, h, w, edge):
+    import importlib
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    himgs, hseeds = _batch_case(s, h, w, 300 + s)
+    got = _run_batch(eng, himgs, hseeds, edge)
+    for k in range(s):
+        want = ol.segment_arrival(himgs[k], hseeds[k], edge=edge)
+        assert got[k].shape == want.shape and (got[k] == want).all(), k
+
+
+def test_segment_batch_unsorted_list_and_bad_seed(pkg):
+    import importlib
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    himgs, hseeds = _batch_case(4, 32, 64, 77)
+    hseeds[2] = hseeds[2][::-1].copy()                      # one list in decreasing order: the painted form, slice by slice
+    got = _run_batch(eng, himgs, hseeds)
+    for k in range(4):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+    hseeds[2] = hseeds[2][::-1].copy()
+    got = _run_batch(eng, himgs, hseeds)                    # sorted again: the context goes back to the stacked form
+    for k in range(4):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+    # a seed below its own slice would land in the next slice of the stack: it must be an error, as in a single call
+    bad = [x.copy() for x in hseeds]
+    bad[1] = np.concatenate([bad[1], [[32, 5]]])
+    with pytest.raises(Exception) as ei:
+        _run_batch(eng, himgs, bad)
+    assert "seed" in str(ei.value).lower()
+    got = _run_batch(eng, himgs, hseeds)                    # and the context is usable afterwards
+    for k in range(4):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
