@@ -76,6 +76,9 @@ def main():
     dev = importlib.import_module("rustronomy_watershed_amd.device")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)      # one rank per GPU on a real node
     torch.cuda.set_device(dev_index)
+    # a real stream for everything (torch's default is the legacy null stream, on which nothing can be captured): the
+    # engine replays the first passes of a transform that repeats the previous one's buffers as one hipGraph launch
+    torch.cuda.set_stream(torch.cuda.Stream(dev_index))
     eng = dev.DeviceEngine(dev_index, engine=pkg.ENGINE_SWEEP if args.engine == "sweep" else pkg.ENGINE_FUSED)
 
     H = W = args.size

@@ -111,6 +111,9 @@ typedef struct ws_stats {
   uint32_t launches_resolve;
   uint32_t launches_sweep;
   uint32_t relax_tile_iterations; /* k_relax2: in-tile sweeps summed over tiles and passes */
+  uint32_t graph_launches;    /* 1: the call's seed tables, first passes and gated resolve ran as one hipGraph launch
+                                 (a transform repeating the previous one's buffers, sizes and seed count, on a
+                                 non-null stream); occupies what was tail padding: the struct size is unchanged */
 } ws_stats;
 
 /* HookCtx (lib.rs:844-862) as a C callback, invoked once per water level, in order.

@@ -45,7 +45,8 @@ class Stats(ctypes.Structure):
                 ("ms_relax", ctypes.c_float), ("ms_resolve", ctypes.c_float), ("ms_sweep", ctypes.c_float),
                 ("ms_other", ctypes.c_float), ("ms_total", ctypes.c_float),
                 ("launches_relax", ctypes.c_uint32), ("launches_resolve", ctypes.c_uint32),
-                ("launches_sweep", ctypes.c_uint32), ("relax_tile_iterations", ctypes.c_uint32)]
+                ("launches_sweep", ctypes.c_uint32), ("relax_tile_iterations", ctypes.c_uint32),
+                ("graph_launches", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

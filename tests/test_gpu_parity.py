@@ -405,3 +405,70 @@ def test_segment_batch_unsorted_list_and_bad_seed(pkg):
     got = _run_batch(eng, himgs, hseeds)                    # and the context is usable afterwards
     for k in range(4):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+
+
+def test_graph_replay_of_repeated_transforms(pkg):
+    """A transform that repeats the previous one's buffers, sizes and seed count replays its first passes as one hipGraph
+    (third call on).  The CONTENTS of the buffers change between the calls: every replay must compute afresh, and a flood
+    that needs more passes than the graph holds must go on with the ordinary loop."""
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    with torch.cuda.stream(torch.cuda.Stream()):      # capture is not allowed on the legacy null stream
+        eng = dev.DeviceEngine(0)
+        h, w = 96, 256
+        imgs = [cases.field(h, w, 500), cases.smooth_field(h, w, 501), cases.field(h, w, 502)]
+        lists = [ol.find_local_minima(a).astype(np.int64).reshape(-1, 2) for a in imgs]
+        # a long corridor (one seed at its end, walls elsewhere): hundreds of rings, far more passes than the graph holds
+        maze = np.full((h, w), 255, np.uint8)
+        for k, y in enumerate(range(2, h - 2, 4)):
+            maze[y, 2:w - 2] = 7
+            maze[y:y + 5, (w - 3) if k % 2 == 0 else 2] = 7
+        imgs.append(maze)
+        lists.append(np.array([[2, 2]], dtype=np.int64))
+        n = min(len(x) for x in lists[:3])
+        d_img = torch.empty((h, w), dtype=torch.uint8, device=eng.device)
+        d_seeds = torch.empty((n, 2), dtype=torch.int32, device=eng.device)
+        out = torch.empty((h, w), dtype=torch.int32, device=eng.device)
+        replays = 0
+        for rep in range(9):
+            k = rep % 3
+            seeds = lists[k][:n]                      # a prefix of a strictly increasing list is strictly increasing
+            d_img.copy_(torch.from_numpy(imgs[k]))
+            d_seeds.copy_(torch.from_numpy(seeds).to(torch.int32))
+            got = eng.segment(d_img, d_seeds, out=out).cpu().numpy().view(np.uint32)
+            replays += eng.stats()["graph_launches"]
+            assert (got == ol.segment_arrival(imgs[k], seeds)).all(), rep
+            if rep in (4, 7):                         # same buffers, the merging transform in between (another key)
+                m = eng.merge(d_img, d_seeds).cpu().numpy().view(np.uint32)
+                assert (m == ol.merge_arrival(imgs[k], seeds)).all(), rep
+        assert replays >= 3, replays
+        # the corridor through the same buffers and seed count 1: replayed graph, gate closed, ordinary loop afterwards
+        d_one = torch.empty((1, 2), dtype=torch.int32, device=eng.device)
+        d_one.copy_(torch.from_numpy(lists[3]).to(torch.int32))
+        d_img.copy_(torch.from_numpy(maze))
+        replays = 0
+        for rep in range(4):
+            got = eng.segment(d_img, d_one, out=out).cpu().numpy().view(np.uint32)
+            replays += eng.stats()["graph_launches"]
+            assert eng.stats()["relax_passes"] > 8
+            assert (got == ol.segment_arrival(maze, lists[3])).all(), rep
+        assert replays >= 2, replays
+        # merging and batches repeat as well (their own keys)
+        d_img.copy_(torch.from_numpy(imgs[0]))
+        d_seeds.copy_(torch.from_numpy(lists[0][:n]).to(torch.int32))
+        mout = torch.empty((h, w), dtype=torch.int32, device=eng.device)
+        for rep in range(4):
+            m = eng.merge(d_img, d_seeds, out=mout).cpu().numpy().view(np.uint32)
+            assert (m == ol.merge_arrival(imgs[0], lists[0][:n])).all(), rep
+        assert eng.stats()["graph_launches"] == 1
+        himgs, hseeds = _batch_case(4, 32, 64, 900)
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
+        cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
+        allseeds = torch.from_numpy(np.concatenate(hseeds).astype(np.int64).reshape(-1, 2)).to(torch.int32).to(eng.device).contiguous()
+        bout = torch.empty((4, 32, 64), dtype=torch.int32, device=eng.device)
+        for rep in range(4):
+            got = eng.segment_batch(cube, allseeds, offs, out=bout).cpu().numpy().view(np.uint32)
+            for k in range(4):
+                assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), (rep, k)
+        assert eng.stats()["graph_launches"] == 1

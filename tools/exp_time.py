@@ -8,6 +8,8 @@ import __graft_entry__ as ge
 ge.build_hip(); ge.load_package()
 import importlib
 dev = importlib.import_module("rustronomy_watershed_amd.device")
+if os.environ.get("WS_OWN_STREAM"):      # torch's default stream is the legacy null stream: no graph capture there
+    torch.cuda.set_stream(torch.cuda.Stream())
 eng = dev.DeviceEngine(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 img = eng.random_field(n, n, 1)
