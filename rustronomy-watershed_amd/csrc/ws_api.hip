@@ -82,6 +82,8 @@ struct ws_ctx {
   uint64_t buffer_generation = 1;    // bumped whenever a device buffer of the context is reallocated
 };
 
+static_assert(sizeof(ws_stats) == 72, "ws_stats is part of the ABI: graph_launches sits in what was tail padding");
+
 namespace {
 
 // flags buffer layout (u32 words); the pinned host mirror uses the same offsets

@@ -106,3 +106,15 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_stats_struct_layout_is_stable():
+    # ws_stats is filled through a caller-provided pointer: its size and the offsets of the old fields are ABI.
+    # graph_launches was added in what used to be tail padding (68 -> 72 bytes were always reserved by alignment).
+    import ctypes
+    import importlib
+    ge.load_package()
+    ffi = importlib.import_module("rustronomy_watershed_amd._ffi")
+    assert ctypes.sizeof(ffi.Stats) == 72
+    assert ffi.Stats.relax_tile_iterations.offset == 64 and ffi.Stats.graph_launches.offset == 68
+    assert ffi.Stats.tiles_run_relax.offset == 16 and ffi.Stats.ms_relax.offset == 32
