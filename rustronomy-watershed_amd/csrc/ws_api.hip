@@ -993,10 +993,8 @@ constexpr int MF_HIST_ED = NLEVELS;
 constexpr int MF_CUR_PX = 2 * NLEVELS;
 constexpr int MF_CUR_ED = 3 * NLEVELS;
 constexpr int MF_LAKE_CURSOR = 4 * NLEVELS;
-constexpr int MF_LAKE_OFFSETS = 4 * NLEVELS + 8;          // NLEVELS + 1 entries
 constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // NLEVELS u32 counters (one per level: no memset between levels)
 constexpr int MF_LAKE_COUNT = 6 * NLEVELS + 16;           // NLEVELS u64 per-level record counters
-constexpr int MF_LAKE_DONE = 7 * NLEVELS + 16;            // NLEVELS u32 finished-workgroup counters
 constexpr int MF_WORDS = 8 * NLEVELS + 24;
 constexpr uint32_t LIST_GROUP = 16;                       // levels per host copy of lake records (16 groups: kern_ev has 64)
 
@@ -1053,12 +1051,13 @@ int level_loop(ws_ctx *c, const LevelBuckets &lb, uint32_t max_level, bool mergi
   const uint2 *edge_items = (const uint2 *)c->edge_items.p;
   for (uint32_t l = 0; l <= max_level; ++l) {
     const size_t e0 = lb.off_ed[l], e1 = lb.off_ed[l + 1], p0 = lb.off_px[l], p1 = lb.off_px[l + 1];
-    if (merging && e1 > e0) {
+    const bool unions = merging && e1 > e0;
+    if (unions) {
       HIP_TRY(c, union_edges(c->stream, edge_items + e0, e1 - e0, parent, want_sizes ? hooked : nullptr, hooked_count + l));
-      if (want_sizes) HIP_TRY(c, fold_sizes(c->stream, hooked, hooked_count + l, parent, size));
       c->stats.merge_levels++;
     }
-    if (want_sizes && p1 > p0) HIP_TRY(c, add_arrivals(c->stream, px_items + p0, p1 - p0, parent, size));
+    // areas of the nodes hooked in this level move to their roots, arriving pixels are counted: one launch
+    if (want_sizes) HIP_TRY(c, fold_and_add(c->stream, unions ? hooked : nullptr, hooked_count + l, px_items + p0, p1 - p0, parent, size));
     int rc = per_level(l);
     if (rc) return rc;
   }
@@ -1109,9 +1108,9 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
 
   rc = level_loop(c, lb, opt->max_water_level, merging, want_list, [&](uint32_t l) -> int {
     if (want_list) {
-      // offsets[l] = records before this level (offsets[0] = 0 from the memset); the kernel stores offsets[l + 1]
-      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_CURSOR,
-                            mf + MF_LAKE_COUNT + l, mf + MF_LAKE_OFFSETS + l + 1, (uint32_t *)(mf + MF_LAKE_DONE) + l));
+      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap,
+                            mf + MF_LAKE_COUNT, l));
       // every LIST_GROUP levels (and after the last): a marker, so that the records of finished levels can travel to
       // the host while later levels are still being computed
       if ((l + 1) % LIST_GROUP == 0 || l == opt->max_water_level) HIP_TRY(c, hipEventRecord(c->kern_ev[l / LIST_GROUP], c->stream));
@@ -1136,8 +1135,9 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
       const uint32_t g1 = std::min(g0 + LIST_GROUP, levels);
       HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g0 / LIST_GROUP], 0));
-      HIP_TRY(c, hipMemcpyAsync(offsets + g0 + 1, mf + MF_LAKE_OFFSETS + g0 + 1, (g1 - g0) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+      HIP_TRY(c, hipMemcpyAsync(offsets + g0 + 1, mf + MF_LAKE_COUNT + g0, (g1 - g0) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
       HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      for (uint32_t l = g0; l < g1; ++l) offsets[l + 1] += offsets[l];      // counts -> offsets
       const size_t end = std::min<size_t>(offsets[g1], cap);
       if (end > copied) {
         HIP_TRY(c, hipMemcpyAsync(lakes + copied, (const ws_lake *)c->lakes.p + copied, (end - copied) * sizeof(ws_lake), hipMemcpyDeviceToHost, c->copy_stream));

@@ -252,6 +252,44 @@ __global__ void k_add_arrivals(const uint32_t *__restrict__ px_items, size_t n, 
   }
 }
 
+// Both of the above in one launch (a level of transform_to_list is four dependent launches of a few microseconds each:
+// launch gaps are most of its time).  They do not interfere: folding reads the areas of nodes hooked in this level --
+// no longer roots, so no arrival is added to them -- and both add to roots.
+__global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
+                               const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size) {
+  const int lane = threadIdx.x & 63;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  if (hooked) {
+    const uint32_t nh = *hooked_count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nh; i += step) {
+      const uint32_t b = hooked[i];
+      const uint32_t area = size[b];
+      if (area) atomicAdd(&size[uf_find(parent, b)], area);
+    }
+  }
+  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < n; base += step) {      // uniform trip count per wave
+    const size_t i = base + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    while (todo != 0) {
+      const int leader = (int)__builtin_ctzll(todo);
+      const uint32_t r0 = __shfl(r, leader, 64);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
+      if (lane == leader) atomicAdd(&size[r0], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
+  }
+}
+
+hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items, size_t n,
+                        uint32_t *parent, uint32_t *size) {
+  if (!hooked && n == 0) return hipSuccess;
+  const size_t want = std::max<size_t>((n + 255) / 256, hooked ? 512 : 1);
+  k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size);
+  return hipGetLastError();
+}
+
 hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -259,38 +297,65 @@ hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint3
   return hipGetLastError();
 }
 
-// lib.rs:628-635 sparsely: one (colour, area) record per lake with area > 0.  Records of one level are
-// contiguous: a record's position is `*total` (records of the earlier levels; nobody writes it while the level's
-// workgroups are busy) plus a ticket from this level's own counter.  The LAST workgroup to finish adds the
-// level's count to `*total` and stores it as the next level's offset -- no separate launch to snapshot a cursor.
-__global__ void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
-                             uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done) {
-  const u64c base = *total;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;     // colour 0 = uncoloured
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (; i < n_colours; i += step) {
-    const uint32_t area = size[i];
-    if (parent[i] == (uint32_t)i && area) {
-      const u64c pos = base + atomicAdd(level_count, 1ull);
-      if (pos < cap) { lakes[2 * pos] = (uint64_t)i; lakes[2 * pos + 1] = (uint64_t)area; }
-    }
+// lib.rs:628-635 sparsely: one (colour, area) record per lake with area > 0.  Records of one level are contiguous:
+// a record's position is the number of records of the earlier levels -- every workgroup adds up their counters, which
+// earlier launches finished -- plus a ticket from this level's own counter, one request per WAVE (its lakes take
+// consecutive records).  No cursor is handed from level to level inside the kernel: the "last workgroup publishes the
+// total" protocol that did that needs __threadfence(), which on this part writes the XCD's L2 back -- 24 us per level
+// for a kernel with 5 us of work, 6 of the 11 ms of a 1024^2 transform_to_list.
+constexpr int EMIT_PER_THREAD = 4;      // colours per thread: a workgroup of 256 looks at 1024 colours and asks for ONE ticket range
+__global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
+                                                    uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level) {
+  __shared__ u64c s_base;
+  __shared__ uint32_t s_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) {
+    u64c before = 0;
+    for (uint32_t j = (uint32_t)lane; j < level; j += 64) before += level_counts[j];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) s_base = before;
   }
+  // same-address atomics retire one per ~10 ns: a ticket request per wave (1.8 k per level at 1024^2) was 17 us of this
+  // kernel; per workgroup of 1024 colours it is ~1 us
+  const size_t i0 = (size_t)blockIdx.x * (256 * EMIT_PER_THREAD) + 1;      // colour 0 = uncoloured
+  uint32_t area[EMIT_PER_THREAD];
+  bool lake[EMIT_PER_THREAD];
+  unsigned long long m[EMIT_PER_THREAD];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < EMIT_PER_THREAD; ++k) {
+    const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
+    area[k] = i < n_colours ? size[i] : 0u;
+    lake[k] = i < n_colours && area[k] != 0u && parent[i] == (uint32_t)i;
+    m[k] = __builtin_amdgcn_ballot_w64(lake[k]);
+    mine += (uint32_t)__popcll(m[k]);
+  }
+  if (lane == 0) s_wave[wave] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(done, 1u) == gridDim.x - 1) {       // every other workgroup has read `*total` and taken its tickets
-      __threadfence();
-      const u64c sum = base + __hip_atomic_load(level_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *total = sum;
-      *next_offset = sum;
+  const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+  const uint32_t block_total = w0 + w1 + w2 + w3;
+  if (block_total == 0) return;            // workgroup uniform
+  __shared__ u64c s_first;
+  if (threadIdx.x == 0) s_first = atomicAdd(level_counts + level, (u64c)block_total);
+  __syncthreads();
+  u64c pos = s_base + s_first + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+#pragma unroll
+  for (int k = 0; k < EMIT_PER_THREAD; ++k) {
+    const u64c p = pos + (u64c)__popcll(m[k] & ((1ull << lane) - 1ull));
+    if (lake[k] && p < cap) {
+      const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
+      lakes[2 * p] = (uint64_t)i;
+      lakes[2 * p + 1] = (uint64_t)area[k];
     }
+    pos += (u64c)__popcll(m[k]);
   }
 }
 
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done) {
-  const int blocks = n_colours <= 1 ? 1 : (int)((n_colours + 255) / 256 < 4096 ? (n_colours + 255) / 256 : 4096);
-  k_emit_lakes<<<blocks, 256, 0, s>>>(parent, size, n_colours, lakes, cap, total, level_count, next_offset, done);
+                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level) {
+  const size_t per_block = 256 * EMIT_PER_THREAD;
+  const size_t blocks = n_colours <= 1 ? 1 : (n_colours - 1 + per_block - 1) / per_block;
+  k_emit_lakes<<<(unsigned)blocks, 256, 0, s>>>(parent, size, n_colours, lakes, cap, level_counts, level);
   return hipGetLastError();
 }
 

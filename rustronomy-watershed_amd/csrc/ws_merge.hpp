@@ -37,11 +37,14 @@ hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *pa
 hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, uint32_t *parent,
                       uint32_t *size);
 hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size);
-// appends (colour, area) of every root with area > 0 at lakes[*cursor ...); counts past cap too
-// total: records emitted by earlier levels; level_count / done: this level's ticket counter and finished-workgroup
-// counter (both zero on entry); next_offset receives total + this level's count
+// fold_sizes (hooked may be null: nothing was hooked in this level) and add_arrivals in one launch
+hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items, size_t n,
+                        uint32_t *parent, uint32_t *size);
+// appends (colour, area) of every root with area > 0 behind the records of the earlier levels; counts past cap too
+// level_counts: one record counter per level, zero on entry; the records of level l start at the sum of
+// level_counts[0 .. l) (earlier launches) and level_counts[l] receives this level's count
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *total, u64c *level_count, u64c *next_offset, uint32_t *done);
+                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level);
 
 // final-only path: union every crossing edge of the whole image in one launch
 // final level only (coloured <=> label != 0); tile_min: union_image_tiles(h, w) words of scratch

@@ -30,3 +30,7 @@ t0 = time.perf_counter(); K = 5
 for _ in range(K): call()
 dt = (time.perf_counter() - t0) / K
 print(f"ws_transform_to_list {m}x{m} (reused buffers): {dt*1e3:.2f} ms, {n.value} records")
+ctx.set_profiling(True)
+call(); call()
+st = ctx.stats()
+print("device ms: total %.2f relax %.2f resolve %.2f other %.2f; merge_levels %d" % (st["ms_total"], st["ms_relax"], st["ms_resolve"], st["ms_other"], st["merge_levels"]))
