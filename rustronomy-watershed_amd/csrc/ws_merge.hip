@@ -212,47 +212,11 @@ hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *pa
   return hipGetLastError();
 }
 
-// after a level's unions: every node hooked in this level hands its accumulated area to its final root
-__global__ void k_fold_sizes(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
-                             uint32_t *parent, uint32_t *size) {
-  const uint32_t n = *hooked_count;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t step = gridDim.x * blockDim.x;
-  for (; i < n; i += step) {
-    const uint32_t b = hooked[i];
-    const uint32_t area = size[b];
-    if (area) atomicAdd(&size[uf_find(parent, b)], area);
-  }
-}
-
-hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, uint32_t *parent,
-                      uint32_t *size) {
-  k_fold_sizes<<<512, 256, 0, s>>>(hooked, hooked_count, parent, size);
-  return hipGetLastError();
-}
-
-// Areas of the pixels arriving at this level go to the lake they arrive in.  Late levels have few lakes,
-// so most lanes of a wave add to the SAME word: the wave adds once per distinct root (leader election by
-// ballot) -- same-address atomics retire one per ~12 ns, and 4000 of them were the whole kernel.
-__global__ void k_add_arrivals(const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size) {
-  const int lane = threadIdx.x & 63;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < n; base += step) {      // uniform trip count per wave
-    const size_t i = base + threadIdx.x;
-    const bool active = i < n;
-    const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
-    while (todo != 0) {
-      const int leader = (int)__builtin_ctzll(todo);
-      const uint32_t r0 = __shfl(r, leader, 64);
-      const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
-      if (lane == leader) atomicAdd(&size[r0], (uint32_t)__popcll(same));
-      todo &= ~same;
-    }
-  }
-}
-
-// Both of the above in one launch (a level of transform_to_list is four dependent launches of a few microseconds each:
+// After a level's unions every node hooked in this level hands its accumulated area to its final root, and the areas
+// of the pixels arriving at this level go to the lake they arrive in.  Late levels have few lakes, so most lanes of a
+// wave add to the SAME word: the wave adds once per distinct root (leader election by ballot) -- same-address atomics
+// retire one per ~12 ns, and 4000 of them were the whole kernel.
+// Both in one launch (a level of transform_to_list was four dependent launches of a few microseconds each:
 // launch gaps are most of its time).  They do not interfere: folding reads the areas of nodes hooked in this level --
 // no longer roots, so no arrival is added to them -- and both add to roots.
 __global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
@@ -287,13 +251,6 @@ hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *h
   if (!hooked && n == 0) return hipSuccess;
   const size_t want = std::max<size_t>((n + 255) / 256, hooked ? 512 : 1);
   k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size);
-  return hipGetLastError();
-}
-
-hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size) {
-  if (n == 0) return hipSuccess;
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  k_add_arrivals<<<blocks, 256, 0, s>>>(px_items, n, parent, size);
   return hipGetLastError();
 }
 

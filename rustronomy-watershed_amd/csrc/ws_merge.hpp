@@ -34,10 +34,7 @@ hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *la
 // lock-free union-by-min of n edges; every node that loses its root status is appended to hooked
 hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *parent, uint32_t *hooked,
                        uint32_t *hooked_count);
-hipError_t fold_sizes(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, uint32_t *parent,
-                      uint32_t *size);
-hipError_t add_arrivals(hipStream_t s, const uint32_t *px_items, size_t n, uint32_t *parent, uint32_t *size);
-// fold_sizes (hooked may be null: nothing was hooked in this level) and add_arrivals in one launch
+// areas of the nodes hooked in this level to their roots (hooked may be null: nothing was hooked) + arriving pixels counted
 hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items, size_t n,
                         uint32_t *parent, uint32_t *size);
 // appends (colour, area) of every root with area > 0 behind the records of the earlier levels; counts past cap too
