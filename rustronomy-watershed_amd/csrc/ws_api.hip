@@ -44,7 +44,7 @@ struct ws_ctx {
   std::string err;
   ws_stats stats{};
 
-  DevBuf img, keys, labels, labels2, stamps, flags, seeds, out64, counts, aux, seed_stack;
+  DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
   DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
@@ -56,7 +56,6 @@ struct ws_ctx {
   std::vector<TimedSpan> spans;
   std::vector<uint64_t> host64;    // hook staging
   std::vector<uint8_t> host_img;
-  std::vector<uint32_t> host_seeds;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
   bool misc_clean = false;      // the error words of the flag block (FLAG_NERR of them) are known to be zero
@@ -548,16 +547,14 @@ int stage_inputs(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
   int rc;
   // seeds: the reference indexes the (padded) plane with the caller's coordinates and panics
   // when they fall outside (lib.rs:1675-1677)
-  c->host_seeds.resize(2 * n_seeds);
-  for (size_t i = 0; i < n_seeds; ++i) {
-    const uint64_t r = seeds_rc[2 * i], cc = seeds_rc[2 * i + 1];
-    if (r >= ph || cc >= pw) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
-    c->host_seeds[2 * i] = (uint32_t)r;
-    c->host_seeds[2 * i + 1] = (uint32_t)cc;
-  }
+  // (checked and narrowed to 32 bits on the device: a seed outside the plane becomes ~0 and raises the seed-error
+  // word of the transform that follows)
   if ((rc = ensure(c, c->seeds, (n_seeds ? n_seeds : 1) * 2 * sizeof(uint32_t)))) return rc;
-  if (n_seeds)
-    HIP_TRY(c, hipMemcpyAsync(c->seeds.p, c->host_seeds.data(), n_seeds * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  if (n_seeds) {
+    if ((rc = ensure(c, c->seeds64, n_seeds * 2 * sizeof(uint64_t)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->seeds64.p, seeds_rc, n_seeds * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, narrow_seeds(c->stream, (const uint64_t *)c->seeds64.p, n_seeds, ph, pw, (uint32_t *)c->seeds.p));
+  }
   *d_seeds = (const uint32_t *)c->seeds.p;
 
   const size_t raw = (h * w ? h * w : 1);
@@ -568,7 +565,8 @@ int stage_inputs(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
     HIP_TRY(c, pad_image(c->stream, (const uint8_t *)c->aux.p, w, (int)h, (int)w, (uint8_t *)c->img.p));
   } else {
     if ((rc = ensure(c, c->img, raw))) return rc;
-    if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    if (h * w && stride == w) HIP_TRY(c, hipMemcpyAsync(c->img.p, img, h * w, hipMemcpyHostToDevice, c->stream));
+    else if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
   }
   *d_img = (const uint8_t *)c->img.p;
   *d_stride = pw;
@@ -710,7 +708,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack,
+  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->seeds64,
                     &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);

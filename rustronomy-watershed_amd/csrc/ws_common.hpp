@@ -68,6 +68,7 @@ hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph
 // seeds of a stack of slices -> seeds of the stacked plane (row + slice * slice_h); slice_first: n_slices + 1 list offsets
 hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
                        int slice_h, int pw, uint32_t *stacked_rc);
+hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst);   // u64 pairs -> u32 pairs, out of plane -> ~0
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);

@@ -425,6 +425,25 @@ hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const 
   return hipGetLastError();
 }
 
+// The host ABI's seeds are pairs of 64-bit words (Rust's (usize, usize)); the engine's are 32-bit.  A coordinate outside
+// the (padded) plane -- the reference panics there, lib.rs:1675-1677 -- becomes ~0, which every seed kernel reports
+// as out of bounds.  (This loop used to run on the host: 5 ms for the 7.3 M seeds of the bench field.)
+__global__ void k_narrow_seeds(const uint64_t *__restrict__ src, size_t n, uint64_t ph, uint64_t pw, uint2 *dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint64_t r = src[2 * i], c = src[2 * i + 1];
+    dst[i] = (r < ph && c < pw) ? make_uint2((uint32_t)r, (uint32_t)c) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  }
+}
+
+hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  k_narrow_seeds<<<blocks, 256, 0, s>>>(src, n, ph, pw, reinterpret_cast<uint2 *>(dst));
+  return hipGetLastError();
+}
+
 __global__ void k_widen(const uint32_t *src, uint64_t *dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
