@@ -1182,7 +1182,9 @@ static int segment_batch_stacked(ws_ctx *c, const uint8_t *d_cube, size_t n_slic
     return WS_OK;
   if (seed_offsets[n_slices] - seed_offsets[0] >= 0xFFFFFFFFull) return WS_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t per_group = std::max<size_t>(1, (0x7FFFFFFFull / plane));      // the two-launch resolve indexes pixels with 31 bits
+  size_t max_px = 0x7FFFFFFFull;      // the two-launch resolve indexes pixels with 31 bits
+  if (const char *e = getenv("WS_BATCH_MAX_PX")) max_px = std::min<size_t>(max_px, (size_t)atoll(e));      // tests: force several groups
+  const size_t per_group = std::max<size_t>(1, max_px / plane);
   std::vector<uint32_t> first;
   for (size_t k0 = 0; k0 < n_slices; k0 += per_group) {
     const size_t g = std::min(per_group, n_slices - k0);
