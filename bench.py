@@ -103,6 +103,7 @@ def main():
         eng.segment(img, seeds, out=labels)
     barrier()
     dt = time.perf_counter() - t0
+    replayed = bool(eng.stats().get("graph_launches", 0))      # of the last timed transform
     # ---- kernel leg: the same `steps` transforms again with a HIP-event pair around every launch
     # (recorded on the stream the kernels run on) for the roofline object ----
     eng.ctx.set_profiling(True)
@@ -153,7 +154,10 @@ def main():
             "config": {"workload": f"{H}x{W} u8 uniform[0,254) random field per GPU, segmenting transform, "
                                    f"max_water_level 254, seeds = find_local_minima ({n_seeds} on rank 0), "
                                    f"engine {args.engine}",
-                       "slices_per_gpu": 1, "parallelism": f"independent slices x{world}", "coloured_px": coloured},
+                       "slices_per_gpu": 1, "parallelism": f"independent slices x{world}", "coloured_px": coloured,
+                       "launch": ("every step runs all of its kernels; the seed tables, the first 6 passes and the resolve "
+                                  "are replayed as one hipGraph because the buffers repeat (stream launches: +1-2 %)")
+                                 if replayed else "stream launches"},
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
