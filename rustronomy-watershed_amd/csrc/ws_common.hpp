@@ -79,7 +79,8 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels = nullptr,    // non-null: pass 0 derives the stamps from this label plane
                       bool seed_bits = false,                   // ... which is one bit per pixel (seed_tables) instead
-                      int slice_h = 0);                         // > 0: the plane is a stack of independent slices of this many rows
+                      int slice_h = 0,                          // > 0: the plane is a stack of independent slices of this many rows
+                      bool carry_checked_later = false);        // the caller's resolve_two_launch(.., carry_flag) looks for ring carries
 
 // label resolve, iterative form (row blocks of a tiled field, planes >= 2^31 pixels): 64x64 tiles
 size_t resolve_tiles(int h, int w);
@@ -93,7 +94,8 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
                               const uint32_t *seed_mask = nullptr, const uint32_t *word_base = nullptr,    // seed_tables() form
                               uint32_t *tile_min = nullptr,       // merging: per 64x64 tile, one lake? + a colour of it (ws_merge.hpp)
                               const uint32_t *gate = nullptr,     // speculative launch: a pass's convergence slot; both kernels leave if it is set
-                              int slice_h = 0);                   // > 0: stack of independent slices (see relax_pass)
+                              int slice_h = 0,                    // > 0: stack of independent slices (see relax_pass)
+                              uint32_t *carry_flag = nullptr);    // set when a stamp carried out of its ring field (relax_pass with fresh_keys leaves the test to this kernel)
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);

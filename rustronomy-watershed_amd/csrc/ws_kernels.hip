@@ -685,7 +685,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
                                                             const uint32_t *__restrict__ word_base, uint32_t *tile_min,
-                                                            const uint32_t *__restrict__ gate, int SH) {
+                                                            const uint32_t *__restrict__ gate, int SH, uint32_t *carry_flag) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   // Speculative launch (ws_api.hip): queued behind a relaxation pass before the host knows whether that pass still
@@ -761,6 +761,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   // root of the in-tile forest (a seed, or a halo cell = where the chain leaves the tile): such a
   // pixel never enters the jumping rounds.  Roots point at themselves.
   uint32_t P[4][4];
+  uint32_t carried = 0;
   uint32_t live = 0;                             // pixels whose pointer may still move
   {
     const u32x4_r up4 = *reinterpret_cast<const u32x4_r *>(&sB[(ly0 - 1) * RL_P + lx0]);
@@ -788,6 +789,9 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
         const uint32_t k = K[r][c];
         // flooded pixels are interior pixels (lib.rs:220-222) with a finite, non-seed stamp
         const uint32_t flood = (uint32_t)(k - 1u < KEY_INF - 1u) & row_int[r] & col_int[c];
+        // a finite stamp of a flooded pixel with ring 0: a carry out of the 24-bit ring field (the relaxation of a whole
+        // transform leaves this test to the one kernel that reads the finished plane)
+        carried |= flood & (uint32_t)((k & RING_MASK) == 0u);
         const uint32_t d = r == 3 ? dn[c] : K[r + 1][c];
         const uint32_t rr = c == 3 ? Rc[r] : K[r][c + 1];
         const uint32_t l = c == 0 ? Lc[r] : K[r][c - 1];
@@ -810,6 +814,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       }
     }
   }
+  if (carry_flag && carried) atomicExch(carry_flag, 1u);      // never taken on sane inputs
   __syncthreads();                               // every stamp has been read: the tile becomes pointers
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -996,7 +1001,7 @@ size_t resolve_ref_capacity(int h, int w) {
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
                               uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min,
-                              const uint32_t *gate, int slice_h) {
+                              const uint32_t *gate, int slice_h, uint32_t *carry_flag) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const int sh = slice_h > 0 ? slice_h : h;
   const size_t n = (size_t)h * w;
@@ -1004,13 +1009,13 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
   if (seed_mask && tile_min)
-    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh);
+    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag);
   else if (seed_mask)
-    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh);
+    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag);
   else if (tile_min)
-    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh);
+    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh, carry_flag);
   else
-    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh);
+    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);

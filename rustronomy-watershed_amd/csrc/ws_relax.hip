@@ -249,7 +249,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
-                                                      const uint32_t *__restrict__ seed_labels, int seed_bits, int SH) {
+                                                      const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -531,9 +531,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
           for (int c = 0; c < RX_P; ++c) if (gx0 + c >= 0 && gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
         }
       }
+      if (check_carry) {               // kernel uniform
 #pragma unroll
-      for (int c = 0; c < RX_P; ++c)   // a finite non-seed stamp with ring 0 can only come from a carry out of the ring field
-        ovf |= (T[r][c] != 0u && T[r][c] < KEY_INF && (T[r][c] & RING_MASK) == 0u);
+        for (int c = 0; c < RX_P; ++c)   // a finite non-seed stamp with ring 0 can only come from a carry out of the ring field
+          ovf |= (T[r][c] != 0u && T[r][c] < KEY_INF && (T[r][c] & RING_MASK) == 0u);
+      }
     }
     e |= 16u;
     // A tile that stopped at the round cap is not a fixpoint of its own pixels: the four tiles of the
@@ -594,8 +596,12 @@ size_t relax_tiles(int h, int w) {
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels, bool seed_bits, int slice_h) {
+                      const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later) {
   const int th = RX_NW * RX_P;
+  // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
+  // true stamp does not exist).  A transform that hands the finished plane to k_resolve_local lets that kernel look for
+  // it, once, instead of every write-back of every pass here (5 VALU ops per pixel in kernels that are VALU-bound).
+  const int check_carry = carry_checked_later ? 0 : 1;
   const int sh = slice_h > 0 ? slice_h : h;
   const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + th - 1) / th;     // grid anchored at (0, 0): even passes
   const int sx = ax + 1, sy = ay + 1;                                 // grid shifted by half a tile: odd passes
@@ -622,16 +628,16 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from) {
     k_relax<RX_NW, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                prev, cur, pf, max_iters, sl, sb, sh);
+                                                                prev, cur, pf, max_iters, sl, sb, sh, check_carry);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
     if (pass < RX_SCAN_FROM_PASS)
       k_relax<RX_NW, true, false><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
     else
       k_relax<RX_NW, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
   }
   return hipGetLastError();
 }
