@@ -395,31 +395,43 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     halo_row.x = halo_row.x ? 0u : KEY_INF; halo_row.y = halo_row.y ? 0u : KEY_INF;
     halo_row.z = halo_row.z ? 0u : KEY_INF; halo_row.w = halo_row.w ? 0u : KEY_INF;
   }
-  // row inside its slice: the four rows of a patch are all above the plane or all from row 0 on
-  const int ry0 = (SH == H || gyb < 0) ? gyb : gyb % SH;
+  // bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224); everything else, and every
+  // seed (stamp 0 < base), is pinned at its current stamp: b = t
 #pragma unroll
-  for (int r = 0; r < RX_P; ++r) {
-    const int gy = gyb + r;
-    const int ry = ry0 + r >= SH ? ry0 + r - SH : ry0 + r;
-    const bool row_ok = gy >= 0 && gy < H, row_int = ry >= 1 && ry < SH - 1 && gy < H;
+  for (int r = 0; r < RX_P; ++r)
 #pragma unroll
-    for (int c = 0; c < RX_P; ++c) {
-      const int gx = gx0 + c;
-      if (!(row_ok && gx >= 0 && gx < W)) T[r][c] = KEY_INF;
-      // bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224);
-      // everything else, and every seed (stamp 0 < base), is pinned at its current stamp: b = t
-      const uint32_t v = B[r][c];
-      const uint32_t base = (row_int && gx >= 1 && gx < W - 1 && v <= max_level) ? ((v << 24) | 1u) : KEY_INF;
-      B[r][c] = min(base, T[r][c]);
+    for (int c = 0; c < RX_P; ++c) B[r][c] = B[r][c] <= max_level ? ((B[r][c] << 24) | 1u) : KEY_INF;
+  // Workgroup uniform: the tile and its halo ring lie strictly inside the image (and the image is not a stack of
+  // slices) -- every pixel is in the plane and interior, none of the masks below can bite.  These kernels are VALU-bound
+  // (VALUBusy 76-84 %, profiles/), and the masks were ~8 ops per pixel of a tile run's ~60.
+  const bool inner = SH == H && x0 >= 1 && x0 + RX_TW <= W - 1 && y0 >= 1 && y0 + TH <= H - 1;
+  if (!inner) {
+    // row inside its slice: the four rows of a patch are all above the plane or all from row 0 on
+    const int ry0 = (SH == H || gyb < 0) ? gyb : gyb % SH;
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      const int gy = gyb + r;
+      const int ry = ry0 + r >= SH ? ry0 + r - SH : ry0 + r;
+      const bool row_ok = gy >= 0 && gy < H, row_int = ry >= 1 && ry < SH - 1 && gy < H;
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) {
+        const int gx = gx0 + c;
+        if (!(row_ok && gx >= 0 && gx < W)) T[r][c] = KEY_INF;
+        if (!(row_int && gx >= 1 && gx < W - 1)) B[r][c] = KEY_INF;
+      }
+      if (!(row_ok && xh_ok)) halo[r] = KEY_INF;
     }
-    if (!(row_ok && xh_ok)) halo[r] = KEY_INF;
-  }
-  {
     const bool ok = gy_halo_raw >= 0 && gy_halo_raw < H;
     if (!(ok && gx0 + 0 >= 0 && gx0 + 0 < W)) halo_row.x = KEY_INF;
     if (!(ok && gx0 + 1 >= 0 && gx0 + 1 < W)) halo_row.y = KEY_INF;
     if (!(ok && gx0 + 2 >= 0 && gx0 + 2 < W)) halo_row.z = KEY_INF;
     if (!(ok && gx0 + 3 >= 0 && gx0 + 3 < W)) halo_row.w = KEY_INF;
+  }
+#pragma unroll
+  for (int r = 0; r < RX_P; ++r)
+#pragma unroll
+    for (int c = 0; c < RX_P; ++c) B[r][c] = min(B[r][c], T[r][c]);
+  {
     if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][lane * RX_P]) = halo_row;
     if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NW + 1][lane * RX_P]) = halo_row;
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
