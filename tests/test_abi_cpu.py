@@ -118,3 +118,14 @@ def test_stats_struct_layout_is_stable():
     assert ctypes.sizeof(ffi.Stats) == 72
     assert ffi.Stats.relax_tile_iterations.offset == 64 and ffi.Stats.graph_launches.offset == 68
     assert ffi.Stats.tiles_run_relax.offset == 16 and ffi.Stats.ms_relax.offset == 32
+
+
+def test_integration_extern_block_lists_every_header_function():
+    # INTEGRATION.md shows the binding a maintainer of the reference would add: it must not fall behind the header
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ws_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"^(?:int|void|const char \*)\s*(ws_[a-z0-9_]+)\(", header, flags=re.M)))
+    assert len(names) >= 25
+    missing = [n for n in names if f"fn {n}(" not in doc]
+    assert not missing, missing
