@@ -963,10 +963,11 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   const size_t region = (size_t)blockIdx.x * (NTHREADS / 64) + wave;
   if (lane == 63) ref_count[region] = incl;
   if (refmask) {
-    uint32_t *dst = ref_list + region * REF_REGION + (incl - cnt);
+    // (pixel, what it refers to): the chase starts at the target without reading the pixel's own label first
+    uint2 *dst = reinterpret_cast<uint2 *>(ref_list) + region * REF_REGION + (incl - cnt);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if ((refmask >> i) & 1u) *dst++ = (uint32_t)((size_t)(gy0 + (i >> 2)) * W + gx0 + (i & 3));
+      if ((refmask >> i) & 1u) *dst++ = make_uint2((uint32_t)((size_t)(gy0 + (i >> 2)) * W + gx0 + (i & 3)), out[i >> 2][i & 3] & ~REF_BIT);
   }
   WS_STAMP(5);
 }
@@ -982,13 +983,13 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
   const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t region = wave0; region < nregions; region += nwaves) {
     const uint32_t count = ref_count[region];
-    const uint32_t *list = ref_list + region * REF_REGION;
+    const uint2 *list = reinterpret_cast<const uint2 *>(ref_list) + region * REF_REGION;
     for (uint32_t j = lane; j < count; j += 64) {
-      const uint32_t i = list[j];
-      uint32_t v = labels[i];
+      const uint2 e = list[j];
+      uint32_t v = e.y | REF_BIT;
       for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
         v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      labels[i] = v;
+      labels[e.x] = v;
     }
   }
 }
@@ -996,7 +997,7 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
 // words of scratch the two-launch resolve needs: a count and a REF_REGION-entry list per wave of k_resolve_local
 size_t resolve_ref_capacity(int h, int w) {
   const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
-  return nregions * (1 + REF_REGION);
+  return nregions * (1 + 2 * REF_REGION);      // a count and REF_REGION (pixel, target) pairs per wave
 }
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
