@@ -242,7 +242,7 @@ __device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t
   __syncthreads();          // the functions are rebuilt by the next call
 }
 
-template <int NW, bool CHUNKED, bool SCAN>
+template <int NW, bool CHUNKED, bool SCAN, bool LITE>
 __global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
 const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
@@ -462,9 +462,9 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   }
   uint32_t iters = 0;
   bool unfinished = max_iters == 0;      // left before the checked sweep came back clean (round cap)
-  for (; max_iters != 0;) {
-    ++iters;
-    bool changed = false, untracked = false;
+  // the three free sweeps of a round, then the band boundary rows are published
+  auto free_sweeps = [&](uint32_t round) {
+    bool untracked = false;
     uint32_t up[RX_P], dn[RX_P], L[RX_P], R[RX_P];
     {
       const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
@@ -478,7 +478,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
     sweep_cols<false, true>(T, B, up, dn, L, R, untracked);       // right
-    const bool long_range = SCAN && iters > RX_SCAN_AFTER;        // workgroup uniform
+    const bool long_range = SCAN && round > RX_SCAN_AFTER;        // workgroup uniform
     if (long_range) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(halo[r], 0, 64), lane, untracked);
@@ -495,6 +495,15 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
     *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
     __syncthreads();
+  };
+  // LITE (passes >= 2: few pixels are still wrong, many flagged tiles need no change at all): the checked sweep comes
+  // FIRST and the free sweeps after it -- a tile that is already a fixpoint leaves after one sweep instead of four.
+  // Same sequence of sweeps as the other order minus the first three; the exit test is the same.
+  for (; max_iters != 0;) {
+    ++iters;
+    if (!LITE) free_sweeps(iters);
+    bool changed = false;
+    uint32_t up[RX_P], dn[RX_P], L[RX_P], R[RX_P];
     {
       const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
       const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
@@ -516,6 +525,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     if (tid == 0) s_flag[(slot + 2) % 3] = 0;
     if (!again) break;
     if (iters >= max_iters) { unfinished = true; break; }
+    if (LITE) free_sweeps(iters);
   }
   uint64_t sum_after = 0;
 #pragma unroll
@@ -638,17 +648,20 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }();
   const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
-  if (pass < chunk_from) {
-    k_relax<RX_NW, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                prev, cur, pf, max_iters, sl, sb, sh, check_carry);
+  if (pass < chunk_from && pass < 2) {
+    k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry);
+  } else if (pass < chunk_from) {
+    k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
     if (pass < RX_SCAN_FROM_PASS)
-      k_relax<RX_NW, true, false><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
+      k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
                                                               pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
     else
-      k_relax<RX_NW, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
+      k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
   }
   return hipGetLastError();
