@@ -452,7 +452,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // exactly when that checked sweep changes nothing in the whole tile: every pixel has then been
   // evaluated against final neighbour values.  Only the checked sweep pays for change tracking, and
   // a tile that was already converged leaves after 4 sweeps instead of 8.
-  {
+  if (!from_labels) {                // (kernel uniform: the pass that creates the stamp plane writes every patch anyway)
     uint64_t sum_before = 0;         // stamps only ever decrease: a 64-bit patch sum tells "changed" exactly
 #pragma unroll
     for (int r = 0; r < RX_P; ++r)
@@ -527,12 +527,15 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     if (iters >= max_iters) { unfinished = true; break; }
     if (LITE) free_sweeps(iters);
   }
-  uint64_t sum_after = 0;
+  bool any_lower = true;             // a pass that creates the stamp plane writes every patch
+  if (!from_labels) {
+    uint64_t sum_after = 0;
 #pragma unroll
-  for (int r = 0; r < RX_P; ++r)
+    for (int r = 0; r < RX_P; ++r)
 #pragma unroll
-    for (int c = 0; c < RX_P; ++c) sum_after += T[r][c];
-  const bool any_lower = from_labels || sum_after != s_sum[tid];   // a pass that creates the stamp plane writes every patch
+      for (int c = 0; c < RX_P; ++c) sum_after += T[r][c];
+    any_lower = sum_after != s_sum[tid];
+  }
   WS_STAMP(2);
 #ifdef WS_DIAG_STAMPS
   if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = iters;
