@@ -299,36 +299,52 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
   if (chunk >= nchunk) return;
   uint32_t *row = sRow[wave];
   *reinterpret_cast<u32x4_z *>(&row[lane * 4]) = u32x4_z{0u, 0u, 0u, 0u};
-  check_seed_slice(seeds, n, ph, pw, chunk, nchunk, lane, flags);
   const unsigned long long p0 = (unsigned long long)chunk * (TAB_WORDS * 32);
   const unsigned long long p1 = p0 + TAB_WORDS * 32 < npx ? p0 + TAB_WORDS * 32 : npx;
+  // The list is read ONCE, and the walk is also the proof that it is strictly increasing and in bounds: the wave takes
+  // the list range [lo, hi) between the lower bounds of its chunk's two ends and checks that every seed in it lies in
+  // the chunk, in the plane, and after its predecessor.  Neighbouring waves compute the bound they share by the same
+  // search on the same list, so the ranges tile [0, n) whatever the list looks like (the last wave takes what is left);
+  // if every range passes, the whole list is strictly increasing.  Anything else raises flags[2] (and flags[0] for a
+  // seed outside the plane) and the caller repeats the transform with paint_labels, whose own checks name the fault.
+  // (A separate pass over the list for these checks was 58 of the kernel's 161 MB.)
   const size_t lo = seed_lower_bound(seeds, n, pw, p0, lane);
+  size_t hi = chunk + 1 == nchunk ? n : seed_lower_bound(seeds, n, pw, p1, lane);
+  bool bad = hi < lo || hi - lo > (size_t)TAB_WORDS * 32;      // more seeds than pixels: not worth walking
+  if (bad) hi = lo;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the zeroed row before the bits
 
   // four windows of 64 seeds per round, all four loads in flight together
-  for (size_t wbase = lo; wbase < n; wbase += 256) {
+  unsigned long long prev_last = 0;      // position of the seed before the round's first (none: the first of the range)
+  bool have_prev = false;
+  for (size_t wbase = lo; wbase < hi; wbase += 256) {
     uint2 win[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const size_t j = wbase + 64 * k + lane;
-      win[k] = seeds[j < n ? j : n - 1];
+      win[k] = seeds[j < hi ? j : hi - 1];
     }
-    bool done = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const size_t j = wbase + 64 * k + lane;
       const unsigned long long pos = seed_pos(win[k], pw);
-      const bool ok = j < n && pos >= p0 && pos < p1;
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-      const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);           // the leading run of seeds inside the chunk
-      if (!done && lane < run && win[k].x < (uint32_t)ph && win[k].y < (uint32_t)pw) {
+      const bool mine = j < hi;
+      const bool inside = win[k].x < (uint32_t)ph && win[k].y < (uint32_t)pw;
+      // predecessor: the lane below, or the last lane of the window before (a clamped lane repeats the last seed: ignored)
+      unsigned long long before = __shfl_up(pos, 1, 64);
+      if (lane == 0) before = prev_last;
+      const bool first_of_range = lane == 0 && !have_prev;
+      if (mine && !inside) atomicExch(&flags[0], 1u);
+      if (mine && (!inside || pos < p0 || pos >= p1 || (!first_of_range && pos <= before))) bad = true;
+      if (mine && inside && pos >= p0 && pos < p1) {
         const uint32_t b = (uint32_t)(pos - p0);
         atomicOr(&row[b >> 5], 1u << (b & 31u));
       }
-      done = done || run < 64;
+      prev_last = __shfl(pos, 63, 64);
+      have_prev = true;
     }
-    if (done) break;
   }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) { flags[1] = 1u; flags[2] = 1u; }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
   // lane l owns words 4l .. 4l+3 of the chunk: exclusive scan of their popcounts = seeds before them

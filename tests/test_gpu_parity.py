@@ -485,3 +485,37 @@ def test_segment_batch_in_several_groups(pkg, monkeypatch):
     got = _run_batch(eng, himgs, hseeds)
     for k in range(7):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+
+
+def test_seed_tables_walk_rejects_every_list_that_is_not_strictly_increasing(pkg):
+    """The side-table builder reads the list once and proves on the way that it is strictly increasing and in bounds
+    (every wave checks the list range between the lower bounds of its 8192-pixel chunk's two ends).  Lists that are
+    sorted almost everywhere must still be caught -- and then give the labels of the general path."""
+    shape = (700, 1100)                                    # 94 chunks of 8192 pixels
+    img = cases.field(*shape, 23)
+    base = np.ascontiguousarray(ol.find_local_minima(img), dtype=np.uint64)
+    pos = base[:, 0] * shape[1] + base[:, 1]
+    cut = int(np.searchsorted(pos, 8192 * 40))             # first seed of chunk 40
+    ws = _seg(pkg, pkg.ENGINE_FUSED)
+    variants = {
+        "halves_swapped": np.concatenate([base[len(base) // 2:], base[: len(base) // 2]]),
+        "far_duplicate": np.concatenate([base[: len(base) // 2], base[10:11], base[len(base) // 2:]]),
+        "swap_across_a_chunk_boundary": np.concatenate([base[: cut - 1], base[cut:cut + 1], base[cut - 1:cut], base[cut + 1:]]),
+        "swap_inside_a_chunk": np.concatenate([base[: cut + 3], base[cut + 4:cut + 5], base[cut + 3:cut + 4], base[cut + 5:]]),
+        "first_two_swapped": np.concatenate([base[1:2], base[0:1], base[2:]]),
+        "one_chunk_repeated": np.concatenate([base[:cut], base[cut - 50:cut], base[cut:]]),
+        "reversed": base[::-1],
+    }
+    for name, seeds in variants.items():
+        assert (ws.transform(img, base) == ol.segment_arrival(img, base)).all()          # the context expects a sorted list again
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        got = ws.transform(img, seeds)
+        assert (got == ol.segment_arrival(img, seeds)).all(), name
+    for name, bad in {
+        "column_outside_in_the_middle": np.concatenate([base[:cut], np.array([[base[cut][0], shape[1] + 3]], np.uint64), base[cut:]]),
+        "row_outside_at_the_end": np.concatenate([base, np.array([[shape[0] + 5, 1]], np.uint64)]),
+        "row_outside_at_the_start": np.concatenate([np.array([[shape[0], 0]], np.uint64), base]),
+    }.items():
+        assert (ws.transform(img, base) == ol.segment_arrival(img, base)).all()
+        with pytest.raises(IndexError):
+            ws.transform(img, np.ascontiguousarray(bad, dtype=np.uint64))
