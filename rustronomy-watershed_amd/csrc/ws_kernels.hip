@@ -871,9 +871,14 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
         // (the asm pins the colour arithmetic here: computed early it holds 16 registers through the rounds)
         asm volatile("" : "+v"(tab_mask[r]), "+v"(tab_base[r]));
         const uint32_t mw = tab_mask[r], wb = tab_base[r], sh = (uint32_t)(g & 31u);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          Lb[r][c] = (seedbits >> (r * 4 + c)) & 1u ? wb + __popc(mw & ((1u << (sh + c)) - 1u)) + 1u : 0u;
+        // colour of the row's first seed; the seeds after it in the row count on from there (one table popcount per
+        // row instead of one per pixel: the kernel is VALU-bound)
+        const uint32_t first = wb + __popc(mw & ((1u << sh) - 1u)) + 1u;
+        const uint32_t nib = (seedbits >> (r * 4)) & 15u;
+        Lb[r][0] = nib & 1u ? first : 0u;
+        Lb[r][1] = nib & 2u ? first + (nib & 1u) : 0u;
+        Lb[r][2] = nib & 4u ? first + __popc(nib & 3u) : 0u;
+        Lb[r][3] = nib & 8u ? first + __popc(nib & 7u) : 0u;
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
