@@ -777,7 +777,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   // root of the in-tile forest (a seed, or a halo cell = where the chain leaves the tile): such a
   // pixel never enters the jumping rounds.  Roots point at themselves.
   uint32_t P[4][4];
-  uint32_t carried = 0;
+  uint32_t carried = 0xFFFFFFFFu;
   uint32_t live = 0;                             // pixels whose pointer may still move
   {
     const u32x4_r up4 = *reinterpret_cast<const u32x4_r *>(&sB[(ly0 - 1) * RL_P + lx0]);
@@ -807,7 +807,8 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
         const uint32_t flood = (uint32_t)(k - 1u < KEY_INF - 1u) & row_int[r] & col_int[c];
         // a finite stamp of a flooded pixel with ring 0: a carry out of the 24-bit ring field (the relaxation of a whole
         // transform leaves this test to the one kernel that reads the finished plane)
-        carried |= flood & (uint32_t)((k & RING_MASK) == 0u);
+        // (smallest, over the flooded pixels, of the ring field moved to the top of the word: 0 = a carry; two ops per pixel)
+        carried = min(carried, (k << 8) | (flood ^ 1u));
         const uint32_t d = r == 3 ? dn[c] : K[r + 1][c];
         const uint32_t rr = c == 3 ? Rc[r] : K[r][c + 1];
         const uint32_t l = c == 0 ? Lc[r] : K[r][c - 1];
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       }
     }
   }
-  if (carry_flag && carried) atomicExch(carry_flag, 1u);      // never taken on sane inputs
+  if (carry_flag && carried == 0u) atomicExch(carry_flag, 1u);      // never taken on sane inputs
   __syncthreads();                               // every stamp has been read: the tile becomes pointers
 #pragma unroll
   for (int r = 0; r < 4; ++r)
