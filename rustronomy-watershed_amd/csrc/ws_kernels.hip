@@ -357,7 +357,11 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
   }
   uint32_t b0 = (uint32_t)lo + incl - cnt;
   // a stack of slices (slice_px % 128 == 0: a lane's four words lie in one slice): list indices count from the slice's first seed
-  if (slice_first) b0 -= slice_first[(p0 + 128ull * (unsigned)lane) / slice_px];
+  if (slice_first) {      // (clamped twice over for lists that are not what they should be: the slice index and the difference)
+    const size_t npx_slices = (size_t)((npx + slice_px - 1) / slice_px);
+    const uint32_t sf = slice_first[min((size_t)((p0 + 128ull * (unsigned)lane) / slice_px), npx_slices)];
+    b0 = b0 >= sf ? b0 - sf : 0u;
+  }
   const u32x4_z bases = u32x4_z{b0, b0 + c0, b0 + c0 + c1, b0 + c0 + c1 + c2};
   const size_t wi = (size_t)(p0 >> 5) + 4 * lane, nwords = (npx + 31) / 32;
   if (wi + 4 <= nwords && ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(word_base)) & 15u) == 0) {
@@ -1009,7 +1013,9 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
     for (uint32_t j = lane; j < count; j += 64) {
       const uint2 e = list[j];
       uint32_t v = e.y | REF_BIT;
-      for (size_t hops = 0; (v & REF_BIT) && hops < n; ++hops)
+      // (the range test: side tables built from a list that turns out not to be strictly increasing can hold any word
+      // as a "colour", also one that looks like a reference -- the transform is repeated, but nothing may fault first)
+      for (size_t hops = 0; (v & REF_BIT) && (v & ~REF_BIT) < n && hops < n; ++hops)
         v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       labels[e.x] = v;
     }

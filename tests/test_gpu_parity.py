@@ -519,3 +519,30 @@ def test_seed_tables_walk_rejects_every_list_that_is_not_strictly_increasing(pkg
         assert (ws.transform(img, base) == ol.segment_arrival(img, base)).all()
         with pytest.raises(IndexError):
             ws.transform(img, np.ascontiguousarray(bad, dtype=np.uint64))
+
+
+def test_segment_batch_stacked_with_an_unsorted_list_does_not_chase_garbage(pkg):
+    # Regression: in the stacked form the side tables subtract every slice's first list index; built from a list that is
+    # not strictly increasing that difference can be any word, also one with the reference bit set, and the reference
+    # chase followed it out of the plane (a GPU memory fault) before the transform was repeated slice by slice.
+    import importlib
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    rng = np.random.default_rng(9)
+    h, w = 32, 184
+    himgs, hseeds = [], []
+    for k, n in enumerate((289, 5, 28)):
+        himgs.append(rng.integers(0, 254, (h, w), dtype=np.uint8))
+        flat = np.sort(rng.choice(h * w, size=n, replace=False))
+        hseeds.append(np.stack([flat // w, flat % w], axis=1).astype(np.int64))
+    hseeds[1] = hseeds[1][::-1].copy()
+    for _ in range(2):
+        got = _run_batch(eng, himgs, hseeds)
+        for k in range(3):
+            assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k].astype(np.uint64))).all(), k
+        # the prediction flipped to "unsorted"; a sorted batch in between flips it back, so that the stacked form is
+        # tried on the unsorted list again
+        sorted_lists = [hseeds[0], hseeds[1][::-1].copy(), hseeds[2]]
+        got = _run_batch(eng, himgs, sorted_lists)
+        for k in range(3):
+            assert (got[k] == ol.segment_arrival(himgs[k], sorted_lists[k].astype(np.uint64))).all(), k

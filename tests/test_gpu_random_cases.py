@@ -120,3 +120,52 @@ def test_random_mazes_long_range_segmenting():
         assert got.shape == want.shape and (got == want).all(), ("maze", case, h, w, n_seeds)
         most_passes = max(most_passes, ws._ctx().stats()["relax_passes"])
     assert most_passes >= 12, most_passes            # the late-pass kernel variants did run
+
+
+def test_random_batches_of_slices_bit_exact():
+    """ws_segment_batch_device on random stacks: shapes that take the stacked form (w' % 4 == 0, h' * w' % 128 == 0) and
+    shapes that do not, sorted and unsorted lists, empty slices, border seeds, edge correction, low water levels."""
+    import importlib
+    import torch
+    ge.build_hip()
+    ge.load_package()
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    rng = np.random.default_rng(77 + int(os.environ.get("WS_TEST_SEED_OFFSET", "0")))
+    for case in range(24):
+        edge = case % 4 == 3
+        s = int(rng.integers(2, 7))
+        if case % 3 == 2:                                  # anything goes: mostly the slice-by-slice loop
+            h, w = int(rng.integers(3, 70)), int(rng.integers(3, 150))
+        else:                                              # padded plane with w' % 4 == 0 and h' * w' % 128 == 0
+            wp = int(rng.integers(2, 48)) * 4
+            need = 128 // np.gcd(128, wp)
+            hp = int(rng.integers(1, max(2, 80 // need))) * need
+            h, w = (hp - 2, wp - 2) if edge else (hp, wp)
+            if h < 1 or w < 1:
+                continue
+        himgs, hseeds = [], []
+        for k in range(s):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                a = rng.integers(0, 254, (h, w), dtype=np.uint8)
+            elif kind == 1:
+                a = (rng.integers(0, 4, (h, w), dtype=np.uint8) * 60).astype(np.uint8)
+            else:
+                a = rng.choice(np.array([0, 255, 17, 200], dtype=np.uint8), (h, w), p=[0.3, 0.2, 0.3, 0.2])
+            n = int(rng.integers(0, max(2, h * w // 10))) if rng.integers(0, 6) else 0
+            flat = np.sort(rng.choice(h * w, size=min(n, h * w), replace=False))
+            sd = np.stack([flat // w, flat % w], axis=1).astype(np.int64).reshape(-1, 2)
+            if case % 5 == 4 and len(sd) > 2 and k == s // 2:
+                sd = sd[::-1].copy()                        # one unsorted list: the whole batch goes slice by slice
+            himgs.append(a)
+            hseeds.append(sd)
+        max_level = int(rng.choice([254, 254, 90, 3]))
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
+        cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
+        allseeds = torch.from_numpy(np.concatenate(hseeds).reshape(-1, 2)).to(torch.int32).to(eng.device).contiguous()
+        if os.environ.get("WS_TEST_TRACE"): print("batch case", case, s, h, w, edge, max_level, [len(x) for x in hseeds], flush=True)
+        got = eng.segment_batch(cube, allseeds, offs, max_level=max_level, edge=edge).cpu().numpy().view(np.uint32)
+        for k in range(s):
+            want = ol.segment_arrival(himgs[k], hseeds[k].astype(np.uint64), max_level=max_level, edge=edge)
+            assert got[k].shape == want.shape and (got[k] == want).all(), (case, k, s, h, w, edge, max_level)
