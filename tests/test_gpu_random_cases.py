@@ -169,3 +169,55 @@ def test_random_batches_of_slices_bit_exact():
         for k in range(s):
             want = ol.segment_arrival(himgs[k], hseeds[k].astype(np.uint64), max_level=max_level, edge=edge)
             assert got[k].shape == want.shape and (got[k] == want).all(), (case, k, s, h, w, edge, max_level)
+
+
+def test_random_call_sequences_on_one_context_bit_exact():
+    """One context on a real stream (graph capture allowed), a random sequence of segmenting / merging / batch calls
+    over a few fixed sets of device buffers whose CONTENTS change: graphs get captured, replayed, retired by other
+    shapes, fed unsorted lists (the replayed tables are then wrong and the transform repeats itself), corridors that
+    need more passes than a graph holds."""
+    import importlib
+    import torch
+    ge.build_hip()
+    ge.load_package()
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    rng = np.random.default_rng(4242 + int(os.environ.get("WS_TEST_SEED_OFFSET", "0")))
+    with torch.cuda.stream(torch.cuda.Stream()):
+        eng = dev.DeviceEngine(0)
+        sets = []
+        for (h, w, n) in ((64, 128, 300), (96, 256, 40), (40, 64, 7)):
+            sets.append({"h": h, "w": w, "n": n,
+                         "img": torch.empty((h, w), dtype=torch.uint8, device=eng.device),
+                         "seeds": torch.empty((n, 2), dtype=torch.int32, device=eng.device),
+                         "out": torch.empty((h, w), dtype=torch.int32, device=eng.device)})
+        replays = 0
+        for call in range(60):
+            st = sets[int(rng.choice([0, 0, 0, 1, 1, 2]))]
+            h, w, n = st["h"], st["w"], st["n"]
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                img = rng.integers(0, 254, (h, w), dtype=np.uint8)
+            elif kind == 1:
+                img = (rng.integers(0, 4, (h, w), dtype=np.uint8) * 60).astype(np.uint8)
+            elif kind == 2:                                  # a corridor: many passes
+                img = np.full((h, w), 255, np.uint8)
+                for k, y in enumerate(range(2, h - 2, 4)):
+                    img[y, 2:w - 2] = 9
+                    img[y:y + 5, (w - 3) if k % 2 == 0 else 2] = 9
+            else:
+                img = rng.choice(np.array([0, 255, 17, 200], dtype=np.uint8), (h, w), p=[0.3, 0.2, 0.3, 0.2])
+            flat = np.sort(rng.choice(h * w, size=n, replace=False))
+            if rng.integers(0, 8) == 0:
+                flat = flat[rng.permutation(n)]              # the list is not sorted this time
+            seeds = np.stack([flat // w, flat % w], axis=1).astype(np.int64)
+            st["img"].copy_(torch.from_numpy(img))
+            st["seeds"].copy_(torch.from_numpy(seeds).to(torch.int32))
+            if rng.integers(0, 4) == 0:
+                got = eng.merge(st["img"], st["seeds"], out=st["out"]).cpu().numpy().view(np.uint32)
+                want = ol.merge_arrival(img, seeds.astype(np.uint64))
+            else:
+                got = eng.segment(st["img"], st["seeds"], out=st["out"]).cpu().numpy().view(np.uint32)
+                want = ol.segment_arrival(img, seeds.astype(np.uint64))
+            replays += eng.stats()["graph_launches"]
+            assert (got == want).all(), (call, h, w, kind)
+        assert replays >= 5, replays
