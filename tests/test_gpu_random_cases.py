@@ -221,3 +221,42 @@ def test_random_call_sequences_on_one_context_bit_exact():
             replays += eng.stats()["graph_launches"]
             assert (got == want).all(), (call, h, w, kind)
         assert replays >= 5, replays
+
+
+def test_random_transform_to_list_bit_exact():
+    """transform_to_list (merging and segmenting) on random small fields against the oracle's per-level lake sizes:
+    plateaus, walls, sorted and shuffled seed lists, edge correction, low and high water levels."""
+    ge.build_hip()
+    pkg = ge.load_package()
+    rng = np.random.default_rng(909 + int(os.environ.get("WS_TEST_SEED_OFFSET", "0")))
+    for case in range(14):
+        h, w = int(rng.integers(3, 40)), int(rng.integers(3, 60))
+        kind = case % 3
+        if kind == 0:
+            img = rng.integers(0, 254, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            img = (rng.integers(0, 4, (h, w), dtype=np.uint8) * 60).astype(np.uint8)
+        else:
+            img = rng.choice(np.array([0, 255, 17, 200], dtype=np.uint8), (h, w), p=[0.3, 0.2, 0.3, 0.2])
+        n = int(rng.integers(1, max(2, h * w // 8)))
+        flat = np.sort(rng.choice(h * w, size=min(n, h * w), replace=False))
+        if case % 4 == 1:
+            flat = flat[rng.permutation(len(flat))]
+        seeds = np.stack([flat // w, flat % w], axis=1).astype(np.uint64)
+        max_level = int(rng.choice([254, 120, 7]))
+        edge = bool(rng.integers(0, 2))
+        merging = case % 2 == 0
+        b = pkg.TransformBuilder.new().set_max_water_lvl(max_level)
+        if edge:
+            b.enable_edge_correction()
+        want = []
+        if merging:
+            ol.merge(img, seeds, max_level=max_level, edge=edge,
+                     hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(ol.canonicalise(c, seeds)[0])))
+            got = b.build_merging().transform_to_list(img, seeds)
+        else:
+            ol.segment(img, seeds, max_level=max_level, edge=edge, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(c)))
+            got = b.build_segmenting().transform_to_list(img, seeds)
+        assert [l for l, _ in got] == list(range(max_level + 1)), (case, merging)
+        for (lvl, hist), wnt in zip(got, want):
+            assert hist.shape == wnt.shape and (hist == wnt).all(), (case, lvl, h, w, merging, edge, max_level)
