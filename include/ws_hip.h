@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 1
+#define WS_ABI_VERSION 2 /* 2: ws_options grew to 8 bytes (seed_shift) */
 
 /* lib.rs:138-141 */
 #define WS_UNCOLOURED 0u
@@ -86,9 +86,15 @@ typedef enum ws_engine {
 /* The runtime options of TransformBuilder (lib.rs:908-923) as plain data. */
 typedef struct ws_options {
   uint8_t max_water_level; /* lib.rs:950; valid 1..=254 */
-  uint8_t edge_correction; /* lib.rs:958; 0/1 */
+  uint8_t edge_correction; /* lib.rs:958; 0/1.  The (h+2) x (w+2) plane of lib.rs:1640-1666 is only ever the shape of the
+                              label plane: the ring of zeros around the image is virtual, no padded image copy is made. */
   uint8_t engine;          /* ws_engine */
   uint8_t tie_rule;        /* WS_TIE_FIRST_DRLU */
+  uint8_t seed_shift;      /* only with edge_correction.  0 (default): seeds index the PADDED plane with the caller's
+                              coordinates, i.e. land one pixel up-left of where they were found -- what the reference does
+                              (lib.rs:1364-1366, 1675-1677: `output[*seed_idx]` on the padded array).  1: every seed is moved by
+                              (+1, +1) onto its own pixel -- what edge correction evidently intends; not reference behaviour. */
+  uint8_t reserved[3];     /* must be zero */
 } ws_options;
 
 typedef struct ws_ctx ws_ctx;
@@ -144,6 +150,9 @@ const char *ws_last_error(const ws_ctx *ctx);
 int ws_ctx_set_profiling(ws_ctx *ctx, int enabled);
 int ws_ctx_get_stats(const ws_ctx *ctx, ws_stats *out);
 int ws_ctx_synchronize(ws_ctx *ctx);
+/* ws_segment_batch_device stacks at most this many pixels into one transform (the stack needs 9 bytes per pixel of
+ * context workspace); larger batches run as several stacks.  0 restores the default, 2^31 - 1, which is also the cap. */
+int ws_ctx_set_batch_pixel_limit(ws_ctx *ctx, size_t max_px);
 
 /* TransformBuilder::build_segmenting / build_merging validation (lib.rs:999-1004, 1026-1030). */
 int ws_options_default(ws_options *out);          /* lib.rs:936-946: max 254, no edge correction */

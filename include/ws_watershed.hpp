@@ -282,6 +282,9 @@ class TransformBuilder {                   // lib.rs:908-1047
   TransformBuilder &set_wlvl_hook(std::function<T(const HookCtx &)> h) { hook_ = std::move(h); return *this; }   // lib.rs:967
   TransformBuilder &set_engine(ws_engine e) { opt_.engine = std::uint8_t(e); return *this; }        // this implementation only
   TransformBuilder &set_context(std::shared_ptr<Context> c) { ctx_ = std::move(c); return *this; }
+  // this implementation only (ws_options.seed_shift): with edge correction, seeds move by (+1, +1) onto their own pixel
+  // instead of indexing the padded plane with the caller's coordinates (lib.rs:1675-1677)
+  TransformBuilder &shift_seeds_into_padded_plane(bool on = true) { opt_.seed_shift = on ? 1 : 0; return *this; }
 
   SegmentingWatershed<T> build_segmenting() const {                                                  // lib.rs:1024-1046
     validate();

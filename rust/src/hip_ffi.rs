@@ -1,0 +1,144 @@
+//! extern "C" declarations of include/ws_hip.h (ABI version 2), one to one.
+//! tests/test_abi_cpu.py checks that no function of the header is missing here.
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const WS_ABI_VERSION: c_int = 2;
+
+#[repr(C)]
+pub struct ws_ctx {
+    _private: [u8; 0],
+}
+
+/// TransformBuilder's runtime options as plain data (8 bytes).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct ws_options {
+    pub max_water_level: u8,
+    pub edge_correction: u8,
+    pub engine: u8,
+    pub tie_rule: u8,
+    /// 0: seeds index the padded plane with the caller's coordinates (reference behaviour); 1: moved by (+1, +1)
+    pub seed_shift: u8,
+    pub reserved: [u8; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct ws_lake {
+    pub colour: u64,
+    pub area: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct ws_stats {
+    pub relax_passes: u32,
+    pub resolve_passes: u32,
+    pub sweep_steps: u32,
+    pub merge_levels: u32,
+    pub tiles_run_relax: u64,
+    pub tiles_run_resolve: u64,
+    pub ms_relax: f32,
+    pub ms_resolve: f32,
+    pub ms_sweep: f32,
+    pub ms_other: f32,
+    pub ms_total: f32,
+    pub launches_relax: u32,
+    pub launches_resolve: u32,
+    pub launches_sweep: u32,
+    pub relax_tile_iterations: u32,
+    pub graph_launches: u32,
+}
+
+pub type ws_level_cb = Option<
+    unsafe extern "C" fn(
+        user: *mut c_void,
+        water_level: u8,
+        max_water_level: u8,
+        image: *const u8,
+        labels: *const u64,
+        h: usize,
+        w: usize,
+    ),
+>;
+
+pub const WS_OK: c_int = 0;
+pub const WS_ERR_BAD_ARG: c_int = -1;
+pub const WS_ERR_MAX_TOO_HIGH: c_int = -2;
+pub const WS_ERR_MAX_TOO_LOW: c_int = -3;
+pub const WS_ERR_SEED_OOB: c_int = -4;
+pub const WS_ERR_HIP: c_int = -5;
+pub const WS_ERR_OOM: c_int = -6;
+pub const WS_ERR_NO_DEVICE: c_int = -7;
+pub const WS_ERR_CAPACITY: c_int = -8;
+pub const WS_ERR_RING_OVERFLOW: c_int = -9;
+pub const WS_ERR_TOO_LARGE: c_int = -10;
+pub const WS_ERR_UNSUPPORTED: c_int = -11;
+
+/// ws_dtype
+pub const WS_F32: c_int = 0;
+pub const WS_F64: c_int = 1;
+pub const WS_I32: c_int = 2;
+pub const WS_U16: c_int = 3;
+pub const WS_I16: c_int = 4;
+pub const WS_U8: c_int = 5;
+
+extern "C" {
+    // ---- context
+    pub fn ws_abi_version() -> c_int;
+    pub fn ws_strerror(status: c_int) -> *const c_char;
+    pub fn ws_ctx_create(device: c_int, out: *mut *mut ws_ctx) -> c_int;
+    pub fn ws_ctx_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut ws_ctx) -> c_int;
+    pub fn ws_ctx_destroy(ctx: *mut ws_ctx);
+    pub fn ws_last_error(ctx: *const ws_ctx) -> *const c_char;
+    pub fn ws_ctx_set_profiling(ctx: *mut ws_ctx, enabled: c_int) -> c_int;
+    pub fn ws_ctx_get_stats(ctx: *const ws_ctx, out: *mut ws_stats) -> c_int;
+    pub fn ws_ctx_synchronize(ctx: *mut ws_ctx) -> c_int;
+    pub fn ws_ctx_set_batch_pixel_limit(ctx: *mut ws_ctx, max_px: usize) -> c_int;
+    pub fn ws_options_default(out: *mut ws_options) -> c_int;
+    pub fn ws_options_validate(opt: *const ws_options) -> c_int;
+
+    // ---- host-buffer entry points: what the shim binds
+    pub fn ws_find_local_minima(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        out_rc: *mut u64, cap: usize, n_found: *mut usize) -> c_int;
+    pub fn ws_segment(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, out_labels: *mut u64) -> c_int;
+    pub fn ws_segment_with_hook(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, cb: ws_level_cb, user: *mut c_void,
+        out_labels: *mut u64) -> c_int;
+    pub fn ws_merge_with_hook(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, cb: ws_level_cb, user: *mut c_void,
+        out_labels: *mut u64) -> c_int;
+    pub fn ws_transform_to_list(ctx: *mut ws_ctx, merging: c_int, img: *const u8, h: usize, w: usize,
+        row_stride: usize, seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, lakes: *mut ws_lake,
+        cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64) -> c_int;
+    pub fn ws_merge_transform_stub(h: usize, w: usize, out_labels: *mut u64) -> c_int;
+    pub fn ws_pre_processor(ctx: *mut ws_ctx, data: *const c_void, dtype: c_int, n_elems: usize, max_value: u8,
+        out: *mut u8) -> c_int;
+
+    // ---- device-resident pipelines: u8 images, u32 (row, col) seed pairs and u32 labels stay in HBM
+    pub fn ws_find_local_minima_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        d_out_rc: *mut u32, cap: usize, n_found: *mut usize) -> c_int;
+    pub fn ws_segment_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_segment_batch_device(ctx: *mut ws_ctx, d_cube: *const u8, n_slices: usize, h: usize, w: usize,
+        row_stride: usize, slice_stride: usize, d_seeds_rc: *const u32, seed_offsets: *const usize,
+        opt: *const ws_options, d_labels: *mut u32, failed_slice: *mut usize) -> c_int;
+    pub fn ws_merge_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_last_arrival_device(ctx: *mut ws_ctx, d_keys: *mut *const u32, h: *mut usize, w: *mut usize) -> c_int;
+    pub fn ws_copy_last_arrival_device(ctx: *mut ws_ctx, d_dst: *mut u32, n_elems: usize) -> c_int;
+    pub fn ws_pre_processor_device(ctx: *mut ws_ctx, d_data: *const c_void, dtype: c_int, n_elems: usize,
+        max_value: u8, d_out: *mut u8) -> c_int;
+    pub fn ws_random_field_device(ctx: *mut ws_ctx, d_img: *mut u8, h: usize, w: usize, row_stride: usize,
+        seed: u64) -> c_int;
+
+    // ---- one field tiled over several GPUs (row blocks with halo rows; the caller exchanges the halos)
+    pub fn ws_block_init(ctx: *mut ws_ctx, h: usize, w: usize, d_seeds_rc: *const u32, d_colours: *const u32,
+        n_seeds: usize, d_keys: *mut u32, d_labels: *mut u32) -> c_int;
+    pub fn ws_block_relax(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        max_water_level: u8, d_keys: *mut u32, changed: *mut c_int) -> c_int;
+    pub fn ws_block_resolve(ctx: *mut ws_ctx, d_keys: *const u32, d_labels: *mut u32, h: usize, w: usize,
+        changed: *mut c_int) -> c_int;
+}

@@ -33,9 +33,17 @@ WS_ENGINE_AUTO, WS_ENGINE_FUSED, WS_ENGINE_SWEEP = 0, 1, 2
 WS_DTYPES = {"float32": 0, "float64": 1, "int32": 2, "uint16": 3, "int16": 4, "uint8": 5}
 
 
+WS_ABI_VERSION = 2
+
+
 class Options(ctypes.Structure):
+    """ws_options of include/ws_hip.h (ABI version 2: 8 bytes)."""
     _fields_ = [("max_water_level", ctypes.c_uint8), ("edge_correction", ctypes.c_uint8),
-                ("engine", ctypes.c_uint8), ("tie_rule", ctypes.c_uint8)]
+                ("engine", ctypes.c_uint8), ("tie_rule", ctypes.c_uint8),
+                ("seed_shift", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 3)]
+
+    def __init__(self, max_water_level=254, edge_correction=0, engine=0, tie_rule=0, seed_shift=0):
+        super().__init__(max_water_level, edge_correction, engine, tie_rule, seed_shift)
 
 
 class Stats(ctypes.Structure):
@@ -69,6 +77,7 @@ SIGNATURES = {
     "ws_ctx_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
     "ws_ctx_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),
     "ws_ctx_synchronize": (ctypes.c_int, [vp]),
+    "ws_ctx_set_batch_pixel_limit": (ctypes.c_int, [vp, sz]),
     "ws_options_default": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_options_validate": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_find_local_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
@@ -109,5 +118,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError here = the library does not export the ABI
             fn.restype = res
             fn.argtypes = args
+        if L.ws_abi_version() != WS_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} speaks ABI version {L.ws_abi_version()}, this binding {WS_ABI_VERSION}: rebuild it")
         _lib = L
     return _lib

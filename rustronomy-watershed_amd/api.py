@@ -115,6 +115,9 @@ class Context:
     def synchronize(self):
         self.check(_ffi.lib().ws_ctx_synchronize(self._h))
 
+    def set_batch_pixel_limit(self, max_px):
+        self.check(_ffi.lib().ws_ctx_set_batch_pixel_limit(self._h, int(max_px)))
+
 
 _default_ctx = None
 
@@ -150,6 +153,7 @@ class TransformBuilder:
         self.wlvl_hook = None                 # lib.rs:944
         self.engine = ENGINE_AUTO
         self.context = None
+        self.seed_shift = False               # lib.rs:1675-1677: seeds are NOT moved into the padded plane
 
     @classmethod
     def new(cls):
@@ -182,8 +186,14 @@ class TransformBuilder:
         self.context = ctx
         return self
 
+    def shift_seeds_into_padded_plane(self, on=True):
+        """Not in the reference (ws_options.seed_shift): with edge correction, move every seed by (+1, +1) onto the
+        pixel it was found at, instead of indexing the padded plane with the caller's coordinates (lib.rs:1675-1677)."""
+        self.seed_shift = bool(on)
+        return self
+
     def _validate(self):
-        opt = _ffi.Options(self.max_water_level, int(self.edge_correction), self.engine, 0)
+        opt = _ffi.Options(self.max_water_level, int(self.edge_correction), self.engine, 0, int(self.seed_shift))
         rc = _ffi.lib().ws_options_validate(ctypes.byref(opt))
         if rc == _ffi.WS_ERR_MAX_TOO_HIGH:
             raise MaxToHigh(self.max_water_level)         # lib.rs:1026-1027

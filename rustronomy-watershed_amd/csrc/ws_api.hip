@@ -62,17 +62,19 @@ struct ws_ctx {
   bool expect_sorted = true;    // the last seed list was strictly increasing: try the side-table form first
   uint32_t *tile_min_out = nullptr;   // merging, final labels: run_fused lets the resolve kernel classify the 64x64 tiles into here
   bool tile_min_filled = false;
+  size_t batch_max_px = 0x7FFFFFFFull;      // largest stack of slices run as one transform (ws_ctx_set_batch_pixel_limit)
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
   // the optimistic part of a transform (seed tables, first passes, gated resolve, read-backs) as a replayable graph
   struct GraphKey {
     const void *img = nullptr, *seeds = nullptr, *labels = nullptr, *slice_first = nullptr, *tile_min = nullptr;
     size_t stride = 0, n_seeds = 0;
     int ph = 0, pw = 0, slice_h = 0;
+    bool padded = false;
     uint32_t max_level = 0;
     uint64_t generation = 0;      // of the context's own buffers (buffer_generation)
     bool operator==(const GraphKey &o) const {
       return generation == o.generation && img == o.img && seeds == o.seeds && labels == o.labels && slice_first == o.slice_first && tile_min == o.tile_min &&
-             stride == o.stride && n_seeds == o.n_seeds && ph == o.ph && pw == o.pw && slice_h == o.slice_h && max_level == o.max_level;
+             stride == o.stride && n_seeds == o.n_seeds && ph == o.ph && pw == o.pw && slice_h == o.slice_h && padded == o.padded && max_level == o.max_level;
     }
   };
   GraphKey graph_key, seen_key;      // of graph_exec / of the previous transform
@@ -81,6 +83,7 @@ struct ws_ctx {
   uint64_t buffer_generation = 1;    // bumped whenever a device buffer of the context is reallocated
 };
 
+static_assert(sizeof(ws_options) == 8, "ws_options is part of the ABI (version 2)");
 static_assert(sizeof(ws_stats) == 72, "ws_stats is part of the ABI: graph_launches sits in what was tail padding");
 
 namespace {
@@ -296,7 +299,9 @@ inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass) {
 // stacked coordinates and slice_first (device) holds every slice's first list index, so that colours restart per slice.
 int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
                    const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted,
-                   int slice_h = 0, const uint32_t *slice_first = nullptr) {
+                   int slice_h = 0, const uint32_t *slice_first = nullptr, bool padded = false) {
+  // padded: edge correction -- d_img is the caller's (ph - 2) x (pw - 2) image (per slice), the ring of zeros around it is
+  // virtual (padded_img_index, ws_common.hpp)
   const size_t n = (size_t)ph * pw;
   const size_t ntiles = (size_t)tiles_of(pw) * tiles_of(ph);
   const size_t nwords = (n + 31) / 32;
@@ -318,11 +323,11 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   // operations: the second such transform captures it, later ones replay (1024^2: 0.141 -> 0.100 ms, 2048^2: 0.162 ->
   // 0.133 ms, 8192^2: -2 %).  The host then looks at the lookahead pass's slot; a flood that needs more passes goes on
   // with the ordinary loop.  Not on the legacy null stream (capture is not allowed there).
-  static const bool use_graph = getenv("WS_NO_GRAPH") == nullptr;      // A/B knob for tools/
+  static const bool use_graph = tuning_env("WS_NO_GRAPH") == nullptr;      // A/B knob for tools/
   int graph_mode = 0;      // 1: replayed, 2: captured now
   ws_ctx::GraphKey key;
   key.img = d_img; key.seeds = d_seeds; key.labels = d_labels; key.slice_first = slice_first; key.tile_min = c->tile_min_out;
-  key.stride = stride; key.n_seeds = n_seeds; key.ph = ph; key.pw = pw; key.slice_h = slice_h; key.max_level = max_level;
+  key.stride = stride; key.n_seeds = n_seeds; key.ph = ph; key.pw = pw; key.slice_h = slice_h; key.padded = padded; key.max_level = max_level;
   key.generation = c->buffer_generation;
   const bool graph_ok = use_graph && c->stream != nullptr && !c->graph_unusable && tables && n != 0 && n < 0x80000000ull && !c->profiling && c->misc_clean &&
                         c->debug_max_iters == 0xFFFFFFFFu;
@@ -347,11 +352,11 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     hipError_t e = seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
                                relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
-      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true);
+      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded);
     const uint32_t last = GRAPH_PASSES - 1;
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
-                             c->tile_min_out, edge_slot(flags, last), slice_h, flags + FLAG_OVERFLOW);
+                             c->tile_min_out, edge_slot(flags, last), slice_h, flags + FLAG_OVERFLOW, flags + FLAG_SEED_ERR);
     if (e == hipSuccess)
       e = hipMemcpyAsync(&c->pinned[FLAG_EDGE + (last % COUNTER_RING) * FLAG_SLOT], edge_slot(flags, last), FLAG_SLOT * sizeof(uint32_t),
                          hipMemcpyDeviceToHost, c->stream);
@@ -399,12 +404,12 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   // convergence slot: when the host then reads that the flood was already at its fixpoint (the bench field: always),
   // the labels are being written while it reads, instead of the GPU idling through the round trip.
   const bool two_launch = n < 0x80000000ull;
-  static const bool no_speculation = getenv("WS_NO_SPECULATION") != nullptr;      // A/B knob for tools/
+  static const bool no_speculation = tuning_env("WS_NO_SPECULATION") != nullptr;      // A/B knob for tools/
   if (two_launch && (rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
   auto resolve = [&](const uint32_t *gate) -> int {
     Span sp(c, KC_RESOLVE);
     HIP_TRY(c, resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
-                                  c->tile_min_out, gate, slice_h, flags + FLAG_OVERFLOW));
+                                  c->tile_min_out, gate, slice_h, flags + FLAG_OVERFLOW, flags + FLAG_SEED_ERR));
     return WS_OK;
   };
   uint32_t speculated_after = 0xFFFFFFFFu, converged_at = 0xFFFFFFFFu;
@@ -417,7 +422,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto launch_pass = [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables, slice_h, two_launch);
+                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded);
   };
   if (graph_mode != 0) {
     // the graph ran seed tables, passes 0 .. GRAPH_PASSES - 1, the gated resolve and the read-backs
@@ -479,13 +484,13 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
 }
 
 int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
-              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels) {
+              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool padded = false) {
   // the side-table form needs nibble-aligned patch rows (W % 4 == 0) and the two-launch resolve
-  static const bool no_tables = getenv("WS_NO_SEED_TABLES") != nullptr;      // A/B knob for tools/
+  static const bool no_tables = tuning_env("WS_NO_SEED_TABLES") != nullptr;      // A/B knob for tools/
   const bool can_tables = !no_tables && (pw & 3) == 0 && (size_t)ph * pw < 0x80000000ull && n_seeds > 0;
   bool mispredicted = false;
-  int rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, can_tables && c->expect_sorted, &mispredicted);
-  if (rc == WS_OK && mispredicted) rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, false, &mispredicted);
+  int rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, can_tables && c->expect_sorted, &mispredicted, 0, nullptr, padded);
+  if (rc == WS_OK && mispredicted) rc = run_fused_form(c, d_img, stride, ph, pw, max_level, d_seeds, n_seeds, d_labels, false, &mispredicted, 0, nullptr, padded);
   return rc;
 }
 
@@ -495,7 +500,7 @@ int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
 // `after_level` (optional) sees the plane after each level's loop (the hook point).
 template <class F>
 int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
-              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, F after_level) {
+              const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, F after_level, bool padded = false) {
   const size_t n = (size_t)ph * pw;
   int rc;
   if ((rc = ensure(c, c->labels2, (n ? n : 1) * sizeof(uint32_t)))) return rc;
@@ -517,7 +522,7 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
       {
         Span sp(c, KC_SWEEP);
         HIP_TRY(c, hipMemsetAsync(flags + FLAG_SWEEP, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(c, flood_step(c->stream, d_img, stride, cur, nxt, ph, pw, lvl, flags + FLAG_SWEEP));
+        HIP_TRY(c, flood_step(c->stream, d_img, stride, cur, nxt, ph, pw, lvl, flags + FLAG_SWEEP, padded));
         c->stats.sweep_steps++;
       }
       HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_SWEEP], flags + FLAG_SWEEP, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -538,7 +543,23 @@ int pick_engine(const ws_options *opt) {
   return opt->engine == WS_ENGINE_SWEEP ? WS_ENGINE_SWEEP : WS_ENGINE_FUSED;
 }
 
-// Uploads a host image (optionally padded) and host seeds; returns device pointers.
+// With edge correction the kernels read the caller's own image through a virtual ring of zeros (padded_img_index):
+// no padded copy exists.  An EMPTY image still has a plane (2 x (w + 2) border pixels, never flooded) and the kernels
+// read a clamped address for border pixels, which must exist: a zeroed block of the context stands in.
+int empty_image_block(ws_ctx *c, const uint8_t **d_img, size_t *d_stride) {
+  int rc;
+  if ((rc = ensure(c, c->img, 16))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->img.p, 0, 16, c->stream));
+  *d_img = (const uint8_t *)c->img.p;
+  *d_stride = 1;
+  return WS_OK;
+}
+
+// lib.rs:1675-1677 indexes the padded plane with the caller's coordinates (seed_shift 0); seed_shift 1 moves every seed
+// by (+1, +1), onto the pixel it was found at.  Only meaningful with edge correction.
+inline uint32_t seed_shift_of(const ws_options *opt) { return opt->edge_correction && opt->seed_shift ? 1u : 0u; }
+
+// Uploads a host image and host seeds; returns device pointers (the image tightly packed, stride w).
 int stage_inputs(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                  size_t n_seeds, const ws_options *opt, size_t ph, size_t pw, const uint8_t **d_img,
                  size_t *d_stride, const uint32_t **d_seeds) {
@@ -553,23 +574,27 @@ int stage_inputs(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
   if (n_seeds) {
     if ((rc = ensure(c, c->seeds64, n_seeds * 2 * sizeof(uint64_t)))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->seeds64.p, seeds_rc, n_seeds * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, narrow_seeds(c->stream, (const uint64_t *)c->seeds64.p, n_seeds, ph, pw, (uint32_t *)c->seeds.p));
+    HIP_TRY(c, narrow_seeds(c->stream, (const uint64_t *)c->seeds64.p, n_seeds, ph, pw, (uint32_t *)c->seeds.p, seed_shift_of(opt)));
   }
   *d_seeds = (const uint32_t *)c->seeds.p;
 
-  const size_t raw = (h * w ? h * w : 1);
-  if (opt->edge_correction) {
-    if ((rc = ensure(c, c->aux, raw))) return rc;
-    if ((rc = ensure(c, c->img, ph * pw))) return rc;
-    if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->aux.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, pad_image(c->stream, (const uint8_t *)c->aux.p, w, (int)h, (int)w, (uint8_t *)c->img.p));
-  } else {
-    if ((rc = ensure(c, c->img, raw))) return rc;
-    if (h * w && stride == w) HIP_TRY(c, hipMemcpyAsync(c->img.p, img, h * w, hipMemcpyHostToDevice, c->stream));
-    else if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
-  }
+  if (h * w == 0) return empty_image_block(c, d_img, d_stride);
+  if ((rc = ensure(c, c->img, h * w))) return rc;
+  if (stride == w) HIP_TRY(c, hipMemcpyAsync(c->img.p, img, h * w, hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
   *d_img = (const uint8_t *)c->img.p;
-  *d_stride = pw;
+  *d_stride = w;
+  return WS_OK;
+}
+
+// Device seed list moved by (+1, +1) into the context's own buffer (seed_shift with edge correction).
+int shifted_seeds(ws_ctx *c, const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt, const uint32_t **out) {
+  *out = d_seeds_rc;
+  if (!seed_shift_of(opt) || n_seeds == 0) return WS_OK;
+  int rc;
+  if ((rc = ensure(c, c->seeds, n_seeds * 2 * sizeof(uint32_t)))) return rc;
+  HIP_TRY(c, shift_seeds(c->stream, d_seeds_rc, n_seeds, 1u, (uint32_t *)c->seeds.p));
+  *out = (const uint32_t *)c->seeds.p;
   return WS_OK;
 }
 
@@ -611,10 +636,10 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
                      HIP_TRY(c, hipStreamSynchronize(c->stream));
                      cb(user, (uint8_t)lvl, opt->max_water_level, himg, c->host64.data(), ph, pw);   // lib.rs:1796-1804
                      return WS_OK;
-                   });
+                   }, opt->edge_correction != 0);
     if (rc) return rc;
   } else {
-    rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, d_labels);
+    rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, d_labels, opt->edge_correction != 0);
     if (rc) return rc;
     if (cb) {
       for (uint32_t lvl = 0; lvl <= opt->max_water_level; ++lvl) {
@@ -665,6 +690,8 @@ int ws_options_default(ws_options *out) {
   out->edge_correction = 0;               // lib.rs:943
   out->engine = WS_ENGINE_AUTO;
   out->tie_rule = WS_TIE_FIRST_DRLU;
+  out->seed_shift = 0;                    // lib.rs:1675-1677: seeds are not moved into the padded plane
+  out->reserved[0] = out->reserved[1] = out->reserved[2] = 0;
   return WS_OK;
 }
 
@@ -673,6 +700,7 @@ int ws_options_validate(const ws_options *opt) {
   if (opt->max_water_level > WS_NORMAL_MAX) return WS_ERR_MAX_TOO_HIGH;     // lib.rs:1026-1027
   if (opt->max_water_level <= WS_ALWAYS_FILL) return WS_ERR_MAX_TOO_LOW;     // lib.rs:1028-1029
   if (opt->edge_correction > 1 || opt->engine > WS_ENGINE_SWEEP || opt->tie_rule != WS_TIE_FIRST_DRLU) return WS_ERR_BAD_ARG;
+  if (opt->seed_shift > 1 || opt->reserved[0] || opt->reserved[1] || opt->reserved[2]) return WS_ERR_BAD_ARG;
   return WS_OK;
 }
 
@@ -689,7 +717,7 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   if (ok && own) ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   if (ok && !own) c->stream = (hipStream_t)stream;
   c->own_stream = own;
-  if (const char *e = std::getenv("WS_DEBUG_MAXIT")) c->debug_max_iters = (uint32_t)std::atoi(e);
+  if (const char *e = tuning_env("WS_DEBUG_MAXIT")) c->debug_max_iters = (uint32_t)std::atoi(e);
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -734,6 +762,12 @@ int ws_ctx_set_profiling(ws_ctx *c, int enabled) {
 int ws_ctx_get_stats(const ws_ctx *c, ws_stats *out) {
   if (!c || !out) return WS_ERR_BAD_ARG;
   *out = c->stats;
+  return WS_OK;
+}
+
+int ws_ctx_set_batch_pixel_limit(ws_ctx *c, size_t max_px) {
+  if (!c) return WS_ERR_BAD_ARG;
+  c->batch_max_px = max_px == 0 ? 0x7FFFFFFFull : std::min<size_t>(max_px, 0x7FFFFFFFull);
   return WS_OK;
 }
 
@@ -821,17 +855,15 @@ int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_
   stats_begin(c);
   const uint8_t *src = d_img;
   size_t src_stride = stride;
-  if (opt->edge_correction) {
-    if ((rc = ensure(c, c->img, ph * pw))) return rc;
-    HIP_TRY(c, pad_image(c->stream, d_img, stride, (int)h, (int)w, (uint8_t *)c->img.p));
-    src = (const uint8_t *)c->img.p;
-    src_stride = pw;
-  }
+  const bool padded = opt->edge_correction != 0;      // the ring of zeros is virtual: no padded copy
+  if (padded && h * w == 0 && (rc = empty_image_block(c, &src, &src_stride))) return rc;
+  const uint32_t *seeds;
+  if ((rc = shifted_seeds(c, d_seeds_rc, n_seeds, opt, &seeds))) return rc;
   if (pick_engine(opt) == WS_ENGINE_SWEEP)
-    rc = run_sweep(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, d_labels,
-                   [](uint32_t, const uint32_t *) { return (int)WS_OK; });
+    rc = run_sweep(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, d_labels,
+                   [](uint32_t, const uint32_t *) { return (int)WS_OK; }, padded);
   else
-    rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, d_labels);
+    rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, d_labels, padded);
   if (rc) return rc;
   return stats_end(c);
 }
@@ -1082,7 +1114,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   uint32_t *seg = (uint32_t *)c->labels.p;
   uint64_t *d_out64 = (uint64_t *)c->out64.p;
   // the flood itself is the segmenting one (same coloured set, same arrival stamps: lib.rs:1394-1438 == 1704-1748)
-  if ((rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, seg))) return rc;
+  if ((rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, seg, opt->edge_correction != 0))) return rc;
   const uint32_t *keys = (const uint32_t *)c->keys.p;
   uint32_t *parent;
   LevelBuckets lb;
@@ -1175,15 +1207,14 @@ static int segment_batch_stacked(ws_ctx *c, const uint8_t *d_cube, size_t n_slic
   size_t ph, pw;
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
   if (rc) return rc;
-  static const bool off = getenv("WS_NO_BATCH_STACK") != nullptr || getenv("WS_NO_SEED_TABLES") != nullptr;      // A/B knobs for tools/
+  static const bool off = tuning_env("WS_NO_BATCH_STACK") != nullptr || tuning_env("WS_NO_SEED_TABLES") != nullptr;      // A/B knobs for tools/
   const size_t plane = ph * pw;
   if (off || n_slices < 2 || pick_engine(opt) != WS_ENGINE_FUSED || !c->expect_sorted || (pw & 3) != 0 || plane == 0 ||
-      plane % 128 != 0 || plane >= 0x40000000ull || (!opt->edge_correction && stride != w))
+      plane % 128 != 0 || plane >= 0x40000000ull || stride != w || h * w == 0)
     return WS_OK;
   if (seed_offsets[n_slices] - seed_offsets[0] >= 0xFFFFFFFFull) return WS_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  size_t max_px = 0x7FFFFFFFull;      // the two-launch resolve indexes pixels with 31 bits
-  if (const char *e = getenv("WS_BATCH_MAX_PX")) max_px = std::min<size_t>(max_px, (size_t)atoll(e));      // tests: force several groups
+  const size_t max_px = c->batch_max_px;      // <= 2^31 - 1: the two-launch resolve indexes pixels with 31 bits
   const size_t per_group = std::max<size_t>(1, max_px / plane);
   std::vector<uint32_t> first;
   for (size_t k0 = 0; k0 < n_slices; k0 += per_group) {
@@ -1191,26 +1222,23 @@ static int segment_batch_stacked(ws_ctx *c, const uint8_t *d_cube, size_t n_slic
     const size_t s0 = seed_offsets[k0], ns = seed_offsets[k0 + g] - s0;
     if (ns == 0) return WS_OK;
     stats_begin(c);
-    const uint8_t *src = d_cube + k0 * h * stride;
-    size_t src_stride = stride;
-    if (opt->edge_correction) {
-      if ((rc = ensure(c, c->img, g * plane))) return rc;
-      for (size_t k = 0; k < g; ++k)
-        HIP_TRY(c, pad_image(c->stream, d_cube + (k0 + k) * h * stride, stride, (int)h, (int)w, (uint8_t *)c->img.p + k * plane));
-      src = (const uint8_t *)c->img.p;
-      src_stride = pw;
-    }
+    const uint8_t *src = d_cube + k0 * h * stride;      // edge correction: the slices' rings of zeros are virtual
+    const size_t src_stride = stride;
     first.resize(g + 1);
     for (size_t k = 0; k <= g; ++k) first[k] = (uint32_t)(seed_offsets[k0 + k] - s0);
     if ((rc = ensure(c, c->seed_stack, (ns * 2 + g + 1) * sizeof(uint32_t)))) return rc;
     uint32_t *stacked = (uint32_t *)c->seed_stack.p, *d_first = stacked + ns * 2;
     HIP_TRY(c, hipMemcpyAsync(d_first, first.data(), (g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, stack_seeds(c->stream, d_seeds_rc + 2 * s0, ns, d_first, g, (int)ph, (int)pw, stacked));
+    HIP_TRY(c, stack_seeds(c->stream, d_seeds_rc + 2 * s0, ns, d_first, g, (int)ph, (int)pw, stacked, seed_shift_of(opt)));
     bool mispredicted = false;
     rc = run_fused_form(c, src, src_stride, (int)(g * ph), (int)pw, opt->max_water_level, stacked, ns, d_labels + k0 * plane, true,
-                        &mispredicted, (int)ph, d_first);
+                        &mispredicted, (int)ph, d_first, opt->edge_correction != 0);
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // `first` is reused by the next group
-    if (rc != WS_OK || mispredicted) { c->err.clear(); return WS_OK; }      // the loop repeats the work and names the slice
+    if (rc != WS_OK || mispredicted) {      // the loop repeats the work and names the slice
+      (void)stats_end(c);                   // closes the span opened above; the loop's transforms keep their own statistics
+      c->err.clear();
+      return WS_OK;
+    }
     c->have_keys = false;      // the stamps are those of a stack, not of an image
     if ((rc = stats_end(c))) return rc;
   }
@@ -1256,24 +1284,22 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   stats_begin(c);
   const uint8_t *src = d_img;
   size_t src_stride = stride;
-  if (opt->edge_correction) {
-    if ((rc = ensure(c, c->img, ph * pw))) return rc;
-    HIP_TRY(c, pad_image(c->stream, d_img, stride, (int)h, (int)w, (uint8_t *)c->img.p));
-    src = (const uint8_t *)c->img.p;
-    src_stride = pw;
-  }
+  const bool padded = opt->edge_correction != 0;
+  if (padded && h * w == 0 && (rc = empty_image_block(c, &src, &src_stride))) return rc;
+  const uint32_t *seeds;
+  if ((rc = shifted_seeds(c, d_seeds_rc, n_seeds, opt, &seeds))) return rc;
   uint32_t *seg = (uint32_t *)c->labels.p;
   if ((rc = ensure(c, c->counts, std::max<size_t>(union_image_tiles((int)ph, (int)pw), 1) * sizeof(uint32_t)))) return rc;
   c->tile_min_out = (uint32_t *)c->counts.p;      // the resolve kernel classifies the tiles while it has them in registers
   c->tile_min_filled = false;
-  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds_rc, n_seeds, seg);
+  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
   c->tile_min_out = nullptr;
   if (rc) return rc;
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
   {
     Span sp(c, KC_OTHER);
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
-    HIP_TRY(c, union_image(c->stream, seg, d_seeds_rc, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
+    HIP_TRY(c, union_image(c->stream, seg, seeds, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
                            c->tile_min_filled));
     HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n));
   }

@@ -14,8 +14,18 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace wsk {
+
+// Debug and A/B knobs (WS_DEBUG_MAXIT, WS_NO_GRAPH, WS_RELAX_P0_ROUNDS ...) exist only in a -DWS_TUNING build, which
+// tools/ makes for its experiments.  The shipped library never reads its environment: an inherited variable must not
+// be able to change what a drop-in transform returns.
+#ifdef WS_TUNING
+inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 
 constexpr uint32_t KEY_INF = 0xFF000000u;   // level 255 can never open (NEVER_FILL, lib.rs:141)
 constexpr uint32_t RING_MASK = 0x00FFFFFFu;
@@ -44,6 +54,17 @@ __device__ __forceinline__ uint32_t xcd_span_index(uint32_t b, uint32_t n) {
   const uint32_t per = n / XCDS;
   return b < per * XCDS ? (b % XCDS) * per + b / XCDS : b;
 }
+
+// Edge correction (lib.rs:1640-1666) floods the image inside a ring of zeros.  The ring is never materialised: its
+// pixels are the border pixels of the (h + 2) x (w + 2) plane, which no flood step ever writes (3x3 windows,
+// lib.rs:220-222) -- their base is KEY_INF whatever the image says -- so only interior pixels' bytes are ever looked at,
+// and logical pixel (y, x) of the plane is image pixel (y - 1, x - 1).  Border pixels read a clamped address.
+// SH: rows per slice of a stacked batch (== H for one image); the image rows of slice k start at k * (SH - 2).
+__device__ __forceinline__ size_t padded_img_index(int gy, int gx, int W, int SH, size_t stride) {
+  const int slice = gy / SH, ry = gy - slice * SH;
+  const int iy = max(min(max(ry, 1), SH - 2) - 1, 0), ix = max(min(max(gx, 1), W - 2) - 1, 0);
+  return ((size_t)slice * (size_t)max(SH - 2, 0) + iy) * stride + ix;
+}
 #endif
 
 struct PassFlags {
@@ -56,7 +77,6 @@ struct PassFlags {
 // --- launch wrappers (ws_kernels.hip) ---------------------------------------------------
 hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
 hipError_t zero3(hipStream_t s, uint32_t *a, size_t na, uint32_t *b, size_t nb, uint32_t *c, size_t nc);   // one launch
-hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst);
 hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,
                          uint32_t *labels, uint32_t *keys, uint32_t *err_flag);
@@ -67,8 +87,9 @@ hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph
                        const uint32_t *slice_first = nullptr, size_t slice_px = 0);     // stack of slices: colours restart in every slice
 // seeds of a stack of slices -> seeds of the stacked plane (row + slice * slice_h); slice_first: n_slices + 1 list offsets
 hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
-                       int slice_h, int pw, uint32_t *stacked_rc);
-hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst);   // u64 pairs -> u32 pairs, out of plane -> ~0
+                       int slice_h, int pw, uint32_t *stacked_rc, uint32_t shift = 0);
+hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst, uint32_t shift = 0);   // u64 pairs -> u32 pairs (+shift), out of plane -> ~0
+hipError_t shift_seeds(hipStream_t s, const uint32_t *src, size_t n, uint32_t shift, uint32_t *dst);          // (r, c) -> (r + shift, c + shift)
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);
@@ -80,7 +101,8 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
                       const uint32_t *seed_labels = nullptr,    // non-null: pass 0 derives the stamps from this label plane
                       bool seed_bits = false,                   // ... which is one bit per pixel (seed_tables) instead
                       int slice_h = 0,                          // > 0: the plane is a stack of independent slices of this many rows
-                      bool carry_checked_later = false);        // the caller's resolve_two_launch(.., carry_flag) looks for ring carries
+                      bool carry_checked_later = false,         // the caller's resolve_two_launch(.., carry_flag) looks for ring carries
+                      bool padded = false);                     // edge correction: img is the caller's (h-2) x (w-2) image, the ring of zeros is virtual
 
 // label resolve, iterative form (row blocks of a tiled field, planes >= 2^31 pixels): 64x64 tiles
 size_t resolve_tiles(int h, int w);
@@ -95,10 +117,11 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
                               uint32_t *tile_min = nullptr,       // merging: per 64x64 tile, one lake? + a colour of it (ws_merge.hpp)
                               const uint32_t *gate = nullptr,     // speculative launch: a pass's convergence slot; both kernels leave if it is set
                               int slice_h = 0,                    // > 0: stack of independent slices (see relax_pass)
-                              uint32_t *carry_flag = nullptr);    // set when a stamp carried out of its ring field (relax_pass with fresh_keys leaves the test to this kernel)
+                              uint32_t *carry_flag = nullptr,     // set when a stamp carried out of its ring field (relax_pass with fresh_keys leaves the test to this kernel)
+                              const uint32_t *seed_err = nullptr);   // seed_tables()' three error words: both kernels leave when the tables are invalid
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
-                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter);
+                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded = false);
 
 // local maxima: count per 1024-px row segment, scan, write
 size_t minima_segments(int h, int w);       // count words (one per row)

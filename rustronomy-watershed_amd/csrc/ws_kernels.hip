@@ -55,25 +55,6 @@ hipError_t zero3(hipStream_t s, uint32_t *a, size_t na, uint32_t *b, size_t nb, 
   return hipGetLastError();
 }
 
-// lib.rs:1650-1666: copy the input into the centre of a zeroed (h+2) x (w+2) plane.
-__global__ void k_pad_image(const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst) {
-  const int pw = w + 2, ph = h + 2;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t n = (size_t)ph * pw, step = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) {
-    const int r = (int)(i / pw), c = (int)(i % pw);
-    const bool inside = r >= 1 && r <= h && c >= 1 && c <= w;
-    dst[i] = inside ? src[(size_t)(r - 1) * src_stride + (c - 1)] : (uint8_t)0;
-  }
-}
-
-hipError_t pad_image(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst) {
-  const size_t n = (size_t)(h + 2) * (w + 2);
-  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
-  k_pad_image<<<blocks, 256, 0, s>>>(src, src_stride, h, w, dst);
-  return hipGetLastError();
-}
-
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -376,7 +357,7 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
 
 static int paint_steps() {
   static const int steps = [] {
-    const char *e = getenv("WS_PAINT_STEPS");      // tuning knob, tools/ only
+    const char *e = tuning_env("WS_PAINT_STEPS");      // tuning knob, tools/ only
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : PAINT_STEPS;
   }();
@@ -421,7 +402,7 @@ hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph
 // k * slice_h rows further down.  A seed outside its own slice must not land in a neighbour: it becomes (~0, ~0), which
 // every seed kernel reports as out of bounds.
 __global__ void k_stack_seeds(const uint2 *__restrict__ seeds, size_t n, const uint32_t *__restrict__ slice_first, size_t n_slices,
-                              int slice_h, int pw, uint2 *out) {
+                              int slice_h, int pw, uint2 *out, uint32_t shift) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
@@ -430,37 +411,58 @@ __global__ void k_stack_seeds(const uint2 *__restrict__ seeds, size_t n, const u
       const size_t mid = (lo + hi) / 2;
       if (slice_first[mid] <= i) lo = mid; else hi = mid;
     }
-    const uint2 rc = seeds[i];
-    const bool ok = rc.x < (uint32_t)slice_h && rc.y < (uint32_t)pw;
+    uint2 rc = seeds[i];
+    // shift: seed_shift with edge correction (ws_hip.h); compared before the add, so that ~0 cannot wrap into the plane
+    const bool ok = rc.x < (uint32_t)slice_h - shift && rc.y < (uint32_t)pw - shift;
+    rc.x += shift; rc.y += shift;
     out[i] = ok ? make_uint2(rc.x + (uint32_t)lo * (uint32_t)slice_h, rc.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
   }
 }
 
 hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
-                       int slice_h, int pw, uint32_t *stacked_rc) {
+                       int slice_h, int pw, uint32_t *stacked_rc, uint32_t shift) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
   k_stack_seeds<<<blocks, 256, 0, s>>>(reinterpret_cast<const uint2 *>(seeds_rc), n, slice_first, n_slices, slice_h, pw,
-                                       reinterpret_cast<uint2 *>(stacked_rc));
+                                       reinterpret_cast<uint2 *>(stacked_rc), shift);
+  return hipGetLastError();
+}
+
+// seed_shift (ws_hip.h): every seed moves by (+shift, +shift); a coordinate that cannot move without wrapping becomes ~0,
+// which every seed kernel reports as out of bounds
+__global__ void k_shift_seeds(const uint2 *__restrict__ src, size_t n, uint32_t shift, uint2 *dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint2 rc = src[i];
+    const bool ok = rc.x < 0xFFFFFFFFu - shift && rc.y < 0xFFFFFFFFu - shift;
+    dst[i] = ok ? make_uint2(rc.x + shift, rc.y + shift) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  }
+}
+
+hipError_t shift_seeds(hipStream_t s, const uint32_t *src, size_t n, uint32_t shift, uint32_t *dst) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  k_shift_seeds<<<blocks, 256, 0, s>>>(reinterpret_cast<const uint2 *>(src), n, shift, reinterpret_cast<uint2 *>(dst));
   return hipGetLastError();
 }
 
 // The host ABI's seeds are pairs of 64-bit words (Rust's (usize, usize)); the engine's are 32-bit.  A coordinate outside
 // the (padded) plane -- the reference panics there, lib.rs:1675-1677 -- becomes ~0, which every seed kernel reports
 // as out of bounds.  (This loop used to run on the host: 5 ms for the 7.3 M seeds of the bench field.)
-__global__ void k_narrow_seeds(const uint64_t *__restrict__ src, size_t n, uint64_t ph, uint64_t pw, uint2 *dst) {
+__global__ void k_narrow_seeds(const uint64_t *__restrict__ src, size_t n, uint64_t ph, uint64_t pw, uint2 *dst, uint64_t shift) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
-    const uint64_t r = src[2 * i], c = src[2 * i + 1];
-    dst[i] = (r < ph && c < pw) ? make_uint2((uint32_t)r, (uint32_t)c) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    const uint64_t r = src[2 * i], c = src[2 * i + 1];      // (ph, pw >= shift: the plane is padded whenever shift is 1)
+    dst[i] = (r < ph - shift && c < pw - shift) ? make_uint2((uint32_t)(r + shift), (uint32_t)(c + shift)) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
   }
 }
 
-hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst) {
+hipError_t narrow_seeds(hipStream_t s, const uint64_t *src, size_t n, size_t ph, size_t pw, uint32_t *dst, uint32_t shift) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
-  k_narrow_seeds<<<blocks, 256, 0, s>>>(src, n, ph, pw, reinterpret_cast<uint2 *>(dst));
+  k_narrow_seeds<<<blocks, 256, 0, s>>>(src, n, ph, pw, reinterpret_cast<uint2 *>(dst), shift);
   return hipGetLastError();
 }
 
@@ -705,9 +707,14 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
                                                             const uint32_t *__restrict__ word_base, uint32_t *tile_min,
-                                                            const uint32_t *__restrict__ gate, int SH, uint32_t *carry_flag) {
+                                                            const uint32_t *__restrict__ gate, int SH, uint32_t *carry_flag,
+                                                            const uint32_t *__restrict__ seed_err) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
+  // Side tables built from a seed list that turned out not to be strictly increasing, or to leave the plane, describe
+  // some other list: nothing may be computed from them (the host repeats the transform once it has read the same words).
+  // k_seed_tables has finished before this kernel starts, so the words are final: [0] out of bounds, [2] not strict.
+  if (TABLES && seed_err && (seed_err[0] | seed_err[2]) != 0u) return;
   // Speculative launch (ws_api.hip): queued behind a relaxation pass before the host knows whether that pass still
   // changed anything.  `gate` is the pass's striped convergence slot: any word set -> not a fixpoint yet, leave.
   if (gate && __builtin_amdgcn_ballot_w64(gate[(threadIdx.x & 63) * STRIPE_STRIDE] != 0u) != 0ull) return;
@@ -1003,8 +1010,9 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 // resolves to.
 __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
-                                const uint32_t *__restrict__ gate) {
+                                const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err) {
   const int lane = threadIdx.x & 63;
+  if (seed_err && (seed_err[0] | seed_err[2]) != 0u) return;      // invalid side tables: k_resolve_local wrote no lists (see there)
   if (gate && __builtin_amdgcn_ballot_w64(gate[lane * STRIPE_STRIDE] != 0u) != 0ull) return;      // see k_resolve_local
   const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t region = wave0; region < nregions; region += nwaves) {
@@ -1013,8 +1021,9 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
     for (uint32_t j = lane; j < count; j += 64) {
       const uint2 e = list[j];
       uint32_t v = e.y | REF_BIT;
-      // (the range test: side tables built from a list that turns out not to be strictly increasing can hold any word
-      // as a "colour", also one that looks like a reference -- the transform is repeated, but nothing may fault first)
+      // A reference points at a pixel with a strictly smaller stamp, so a chain visits a pixel at most once: fewer than n
+      // hops.  The range test and the hop bound are belt and braces: with invalid side tables (the only source of words
+      // that are not colours or references of this plane) both resolve kernels have already left.
       for (size_t hops = 0; (v & REF_BIT) && (v & ~REF_BIT) < n && hops < n; ++hops)
         v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       labels[e.x] = v;
@@ -1030,7 +1039,7 @@ size_t resolve_ref_capacity(int h, int w) {
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
                               uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min,
-                              const uint32_t *gate, int slice_h, uint32_t *carry_flag) {
+                              const uint32_t *gate, int slice_h, uint32_t *carry_flag, const uint32_t *seed_err) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const int sh = slice_h > 0 ? slice_h : h;
   const size_t n = (size_t)h * w;
@@ -1038,17 +1047,17 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
   if (seed_mask && tile_min)
-    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag);
+    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag, seed_err);
   else if (seed_mask)
-    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag);
+    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag, seed_err);
   else if (tile_min)
-    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh, carry_flag);
+    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh, carry_flag, nullptr);
   else
-    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag);
+    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag, nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr);
   return hipGetLastError();
 }
 
@@ -1067,7 +1076,7 @@ __device__ __forceinline__ uint32_t pick_drlu(uint32_t d, uint32_t r, uint32_t l
 // was coloured" word is a plain idempotent store (one shared atomic per workgroup would serialise).
 __global__ __launch_bounds__(256) void k_flood_step(const uint8_t *__restrict__ img, size_t img_stride,
                                                     const uint32_t *__restrict__ lin, uint32_t *__restrict__ lout,
-                                                    int H, int W, uint32_t level, uint32_t *counter) {
+                                                    int H, int W, uint32_t level, uint32_t *counter, int pad) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int xc = min(x, W - 1), yc = min(y, H - 1);
@@ -1075,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_flood_step(const uint8_t *__restrict__ 
   const uint32_t c = lin[(size_t)yc * W + xc];
   const uint32_t d = lin[(size_t)yp * W + xc], r = lin[(size_t)yc * W + xp];
   const uint32_t l = lin[(size_t)yc * W + xm], u = lin[(size_t)ym * W + xc];
-  const uint32_t v = img[(size_t)yc * img_stride + xc];
+  const uint32_t v = img[pad ? padded_img_index(yc, xc, W, H, img_stride) : (size_t)yc * img_stride + xc];      // pad: virtual ring of zeros (ws_common.hpp)
   const bool floodable = c == 0u && y >= 1 && y < H - 1 && x >= 1 && x < W - 1 && v <= level;   // lib.rs:224-226
   const uint32_t pick = floodable ? pick_drlu(d, r, l, u) : 0u;
   if (x < W && y < H) lout[(size_t)y * W + x] = c ? c : pick;
@@ -1113,14 +1122,14 @@ __global__ __launch_bounds__(256) void k_flood_step4(const uint8_t *__restrict__
 }
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
-                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter) {
+                      uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded) {
   if (h == 0 || w == 0) return hipSuccess;
-  if ((w & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0) {
+  if (!padded && (w & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0) {
     dim3 grid((w / 4 + 255) / 256, h);
     k_flood_step4<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
   } else {
     dim3 grid((w + 63) / 64, (h + 3) / 4);
-    k_flood_step<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter);
+    k_flood_step<<<grid, 256, 0, s>>>(img, img_stride, lin, lout, h, w, level, counter, padded ? 1 : 0);
   }
   return hipGetLastError();
 }

@@ -85,6 +85,7 @@ __device__ __forceinline__ uint32_t plane_or_bit(const uint32_t *src, size_t p, 
 
 typedef uint32_t patch_t[RX_P][RX_P];
 
+
 // A sweep walks the patch rows (or columns) in its direction and, inside a row, the pixels left to right
 // (top to bottom), every pixel seeing its neighbours as they are NOW -- Gauss-Seidel all the way.  (Any
 // order is a valid relaxation; taking a row's "old" left/right values instead cost 40 register copies
@@ -249,7 +250,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int shifted, int chunk, uint32_t max_level, uint32_t pass,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
-                                                      const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry) {
+                                                      const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
+                                                      int pad) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -318,7 +320,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // as aligned dwords -> one 16-byte stamp load and one 4-byte image load per lane and row
   // (patches outside the plane read a clamped address and are masked afterwards: with W % 4 == 0 a
   // patch is either wholly inside or wholly outside)
-  const bool fast = W >= RX_P && ((x0 >= 0 && x0 + RX_TW <= W) || (W & 3) == 0) &&
+  // (pad: the image is the caller's unpadded one, read through padded_img_index -- byte loads)
+  const bool fast = !pad && W >= RX_P && ((x0 >= 0 && x0 + RX_TW <= W) || (W & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
   const int gxc0 = min(max(gx0, 0), max(W - RX_P, 0));
   // tile halo columns: lanes 0..31 fetch the column left of the tile, lanes 32..63 the one right of
@@ -376,7 +379,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       for (int c = 0; c < RX_P; ++c) {
         const int gxc = min(max(gx0 + c, 0), W - 1);
         T[r][c] = plane_or_bit(ksrc, (size_t)gyc * W + gxc, seed_bits);
-        B[r][c] = img[(size_t)gyc * img_stride + gxc];
+        B[r][c] = img[pad ? padded_img_index(gyc, gxc, W, SH, img_stride) : (size_t)gyc * img_stride + gxc];
       }
       halo[r] = plane_or_bit(ksrc, (size_t)gyc * W + xh, seed_bits);
     }
@@ -621,8 +624,9 @@ size_t relax_tiles(int h, int w) {
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later) {
+                      const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded) {
   const int th = RX_NW * RX_P;
+  const int pad = padded ? 1 : 0;
   // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
   // true stamp does not exist).  A transform that hands the finished plane to k_resolve_local lets that kernel look for
   // it, once, instead of every write-back of every pass here (5 VALU ops per pixel in kernels that are VALU-bound).
@@ -640,32 +644,32 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   // anyway (a capped tile raises all four of its quadrant flags), so its last round -- the one that
   // finds nothing left to do, a third of its time on the bench field -- is not worth running.
   static const uint32_t p0_rounds = [] {
-    const char *e = getenv("WS_RELAX_P0_ROUNDS");        // tuning knob, tools/ only
+    const char *e = tuning_env("WS_RELAX_P0_ROUNDS");        // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 2u;
   }();
   if (pass == 0 && p0_rounds < max_iters) max_iters = p0_rounds;
   // passes 0 and 1 run every tile and pass 2 about half of them (bench field): one tile per workgroup
   static const uint32_t chunk_from = [] {
-    const char *e = getenv("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
+    const char *e = tuning_env("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 3u;
   }();
   const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < 2) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
     if (pass < RX_SCAN_FROM_PASS)
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad);
     else
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad);
   }
   return hipGetLastError();
 }

@@ -23,8 +23,8 @@ class DeviceEngine:
         self.ctx = Context(device_index, stream=self.stream.cuda_stream)
         self.engine = engine
 
-    def options(self, max_level=254, edge=False, engine=None):
-        return _ffi.Options(max_level, int(edge), self.engine if engine is None else engine, 0)
+    def options(self, max_level=254, edge=False, engine=None, seed_shift=False):
+        return _ffi.Options(max_level, int(edge), self.engine if engine is None else engine, 0, int(seed_shift))
 
     def random_field(self, h, w, seed):
         img = torch.empty((h, w), dtype=torch.uint8, device=self.device)
@@ -45,20 +45,20 @@ class DeviceEngine:
         e = 2 if edge else 0
         return img.shape[0] + e, img.shape[1] + e
 
-    def segment(self, img, seeds, max_level=254, edge=False, engine=None, out=None):
+    def segment(self, img, seeds, max_level=254, edge=False, engine=None, out=None, seed_shift=False):
         assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
         assert seeds.dtype == torch.int32 and seeds.is_cuda and (seeds.numel() == 0 or seeds.is_contiguous())
         h, w = img.shape
         if out is None:
             out = torch.empty(self._plane(img, edge), dtype=torch.int32, device=self.device)
-        opt = self.options(max_level, edge, engine)
+        opt = self.options(max_level, edge, engine, seed_shift)
         ns = seeds.shape[0] if seeds.dim() == 2 else 0
         self.ctx.check(_ffi.lib().ws_segment_device(self.ctx.handle, img.data_ptr(), h, w, w,
                                                     seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),
                                                     out.data_ptr()))
         return out
 
-    def segment_batch(self, cube, seeds, seed_offsets, max_level=254, edge=False, out=None):
+    def segment_batch(self, cube, seeds, seed_offsets, max_level=254, edge=False, out=None, seed_shift=False):
         """A stack of independent slices (config C4).  cube: (S, H, W) uint8; seeds: all slices' (row, col) pairs
         concatenated, int32 (n, 2); seed_offsets: S + 1 host integers.  Returns (S, H', W') int32 labels."""
         assert cube.dtype == torch.uint8 and cube.dim() == 3 and cube.is_contiguous() and cube.is_cuda
@@ -68,7 +68,7 @@ class DeviceEngine:
         e = 2 if edge else 0
         if out is None:
             out = torch.empty((s, h + e, w + e), dtype=torch.int32, device=self.device)
-        opt = self.options(max_level, edge)
+        opt = self.options(max_level, edge, None, seed_shift)
         offs = (ctypes.c_size_t * (s + 1))(*[int(x) for x in seed_offsets])
         failed = ctypes.c_size_t(0)
         self.ctx.check(_ffi.lib().ws_segment_batch_device(self.ctx.handle, cube.data_ptr(), s, h, w, w, h * w,
@@ -76,12 +76,12 @@ class DeviceEngine:
                                                           ctypes.byref(opt), out.data_ptr(), ctypes.byref(failed)))
         return out
 
-    def merge(self, img, seeds, max_level=254, edge=False, out=None):
+    def merge(self, img, seeds, max_level=254, edge=False, out=None, seed_shift=False):
         assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
         h, w = img.shape
         if out is None:
             out = torch.empty(self._plane(img, edge), dtype=torch.int32, device=self.device)
-        opt = self.options(max_level, edge)
+        opt = self.options(max_level, edge, None, seed_shift)
         ns = seeds.shape[0] if seeds.dim() == 2 else 0
         self.ctx.check(_ffi.lib().ws_merge_device(self.ctx.handle, img.data_ptr(), h, w, w,
                                                   seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),

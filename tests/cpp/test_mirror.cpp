@@ -3,6 +3,7 @@
 // runs the quickstart on device 0 and checks it against the CPU oracle (test infrastructure).
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../include/ws_watershed.hpp"
@@ -106,9 +107,121 @@ static int gpu_checks() {
   return 0;
 }
 
+// The Rust shim (rust/src/watershed_hip.rs + shim.rs) cannot be compiled in this image.  This function makes the
+// same C-ABI calls in the same order with the same arguments the shim makes for each public method, in plain C
+// style, and checks every result against the oracle -- so the sequence is at least executed.  Comments name the
+// Rust function each block stands for.
+static int shim_sequence_checks() {
+  const size_t H = 150, W = 212;
+  std::vector<uint8_t> img(H * W);
+  ws_or_random_field(img.data(), H, W, 11);
+  // shim::HipCtx::new: ABI version check, then ws_ctx_create
+  CHECK(ws_abi_version() == WS_ABI_VERSION);
+  ws_ctx *ctx = nullptr;
+  CHECK(ws_ctx_create(0, &ctx) == WS_OK);
+
+  // WatershedUtils::find_local_minima: cap = one maximum per 2x2 block
+  const size_t cap = ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+  std::vector<uint64_t> rc_pairs(2 * cap);
+  size_t n = 0;
+  CHECK(ws_find_local_minima(ctx, img.data(), H, W, W, rc_pairs.data(), cap, &n) == WS_OK);
+  std::vector<uint64_t> want_rc(2 * H * W);
+  CHECK(ws_or_find_local_minima(img.data(), H, W, want_rc.data(), H * W) == n);
+  CHECK(std::memcmp(rc_pairs.data(), want_rc.data(), 2 * n * 8) == 0);
+
+  // SegmentingWatershed::transform: Options::ffi() + ws_segment into a zeroed Array2<usize>
+  ws_options o{};
+  o.max_water_level = 254; o.edge_correction = 0; o.engine = 0; o.tie_rule = 0; o.seed_shift = 0;
+  std::vector<uint64_t> out(H * W, 0), want(H * W);
+  CHECK(ws_segment(ctx, img.data(), H, W, W, rc_pairs.data(), n, &o, out.data()) == WS_OK);
+  CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 0, want.data(), nullptr) == 0);
+  CHECK(out == want);
+
+  // Watershed::transform_history (run_with_hook + history_hook + shim::trampoline): per level a copy of the plane;
+  // edge correction on, so planes are (H + 2) x (W + 2) and seeds index the padded plane unshifted (lib.rs:1675-1677)
+  struct Hist { std::vector<std::vector<uint64_t>> planes; std::vector<uint8_t> levels; size_t h = 0, w = 0; } got_h, want_h;
+  auto keep = [](void *u, uint8_t lvl, uint8_t, const uint8_t *, const uint64_t *lab, size_t h, size_t w) {
+    Hist *hs = static_cast<Hist *>(u);
+    hs->planes.emplace_back(lab, lab + h * w);
+    hs->levels.push_back(lvl);
+    hs->h = h; hs->w = w;
+  };
+  o.max_water_level = 37; o.edge_correction = 1;
+  CHECK(ws_segment_with_hook(ctx, img.data(), H, W, W, rc_pairs.data(), n, &o, keep, &got_h, nullptr) == WS_OK);
+  std::vector<uint64_t> scratch((H + 2) * (W + 2));
+  CHECK(ws_or_segment(img.data(), H, W, rc_pairs.data(), n, 37, 1, WS_OR_TIE_FIRST, 0, scratch.data(), nullptr, nullptr, keep, &want_h, nullptr) == 0);
+  CHECK(got_h.planes.size() == 38 && got_h.h == H + 2 && got_h.w == W + 2 && got_h.levels == want_h.levels);
+  CHECK(got_h.planes == want_h.planes);
+
+  // the same with ws_options.seed_shift = 1 (TransformBuilder::shift_seeds_into_padded_plane): equal to the
+  // reference behaviour on seeds moved by (+1, +1)
+  std::vector<uint64_t> moved(rc_pairs.begin(), rc_pairs.begin() + 2 * n);
+  for (uint64_t &v : moved) v += 1;
+  o.max_water_level = 254; o.seed_shift = 1;
+  std::vector<uint64_t> pout((H + 2) * (W + 2)), pwant((H + 2) * (W + 2));
+  CHECK(ws_segment(ctx, img.data(), H, W, W, rc_pairs.data(), n, &o, pout.data()) == WS_OK);
+  CHECK(ws_or_segment_arrival(img.data(), H, W, moved.data(), n, 254, 1, pwant.data(), nullptr) == 0);
+  CHECK(pout == pwant);
+  o.seed_shift = 0;
+
+  // Watershed::transform_to_list (run_to_list): first guess too small on purpose -> WS_ERR_CAPACITY with the exact
+  // count -> second call; then the dense expansion to Vec<usize> of length pixels + 1
+  o.max_water_level = 50; o.edge_correction = 0;
+  std::vector<uint64_t> offsets(52), uncoloured(51);
+  size_t n_lakes = 0, lcap = 16;
+  std::vector<ws_lake> lakes(lcap);
+  int rc = ws_transform_to_list(ctx, 1, img.data(), H, W, W, rc_pairs.data(), n, &o, lakes.data(), lcap, &n_lakes, offsets.data(), uncoloured.data());
+  CHECK(rc == WS_ERR_CAPACITY && n_lakes > lcap);
+  lcap = n_lakes;
+  lakes.assign(lcap, ws_lake{});
+  CHECK(ws_transform_to_list(ctx, 1, img.data(), H, W, W, rc_pairs.data(), n, &o, lakes.data(), lcap, &n_lakes, offsets.data(), uncoloured.data()) == WS_OK);
+  struct Lists { std::vector<std::vector<uint64_t>> v; } want_l;
+  auto sizes = [](void *u, uint8_t, uint8_t, const uint8_t *, const uint64_t *lab, size_t h, size_t w) {
+    std::vector<uint64_t> hist(h * w + 1);
+    ws_or_find_lake_sizes(lab, h * w, hist.data());
+    static_cast<Lists *>(u)->v.push_back(std::move(hist));
+  };
+  CHECK(ws_or_merge_arrival(img.data(), H, W, rc_pairs.data(), n, 50, 0, want.data(), sizes, &want_l) == 0);
+  CHECK(want_l.v.size() == 51);
+  for (size_t l = 0; l < 51; ++l) {
+    std::vector<uint64_t> dense(H * W + 1, 0);
+    dense[0] = uncoloured[l];
+    for (uint64_t k = offsets[l]; k < offsets[l + 1]; ++k) dense[lakes[k].colour] = lakes[k].area;
+    CHECK(dense == want_l.v[l]);
+  }
+
+  // MergingWatershed::transform_final: ws_merge_with_hook, no callback, final labels out
+  CHECK(ws_merge_with_hook(ctx, img.data(), H, W, W, rc_pairs.data(), n, &o, nullptr, nullptr, out.data()) == WS_OK);
+  CHECK(out == want);
+  // MergingWatershed::transform: the reference's stub
+  CHECK(ws_merge_transform_stub(H, W, out.data()) == WS_OK);
+  ws_or_merge_transform_stub(H, W, want.data());
+  CHECK(out == want);
+
+  // WatershedUtils::pre_processor_with_max::<MAX>: f32 goes through as WS_F32, an unlisted type as f64
+  std::vector<float> f(H * W);
+  for (size_t i = 0; i < f.size(); ++i) f[i] = (float)((int)(i % 977) - 300) * 0.37f;
+  f[5] = 0.0f; f[6] = std::numeric_limits<float>::infinity(); f[7] = -std::numeric_limits<float>::infinity();
+  f[8] = std::numeric_limits<float>::quiet_NaN();
+  std::vector<uint8_t> q(f.size()), qw(f.size());
+  CHECK(ws_pre_processor(ctx, f.data(), WS_F32, f.size(), 200, q.data()) == WS_OK);
+  CHECK(ws_or_pre_processor(f.data(), 0, f.size(), 200, qw.data()) == 0);
+  CHECK(q == qw);
+
+  // shim::check: WS_ERR_SEED_OOB becomes the reference's index panic (lib.rs:1676)
+  const uint64_t bad[2] = {H, 0};
+  o.max_water_level = 254;
+  CHECK(ws_segment(ctx, img.data(), H, W, W, bad, 1, &o, out.data()) == WS_ERR_SEED_OOB);
+  CHECK(std::strlen(ws_last_error(ctx)) > 0);
+  // HipCtx::drop
+  ws_ctx_destroy(ctx);
+  std::printf("shim sequence ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   if (cpu_checks()) return 1;
-  if (gpu) return gpu_checks();
+  if (gpu) return gpu_checks() || shim_sequence_checks();
   return no_device_check();
 }

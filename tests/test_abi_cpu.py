@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(pkg):
     raw = ctypes.CDLL(pkg._ffi.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert pkg._ffi.lib().ws_abi_version() == 1
+    assert pkg._ffi.lib().ws_abi_version() == pkg._ffi.WS_ABI_VERSION == 2
 
 
 def test_options_default_and_validation(pkg):
@@ -55,6 +55,28 @@ def test_options_default_and_validation(pkg):
         opt.max_water_level = v
         assert L.ws_options_validate(ctypes.byref(opt)) == pkg._ffi.WS_ERR_MAX_TOO_LOW
     assert b"254" in L.ws_strerror(pkg._ffi.WS_ERR_MAX_TOO_HIGH)
+    # ABI version 2: 8 bytes, seed_shift (default 0 = lib.rs:1675-1677, seeds not moved into the padded plane) + reserved
+    assert ctypes.sizeof(pkg._ffi.Options) == 8 and pkg._ffi.Options.seed_shift.offset == 4
+    L.ws_options_default(ctypes.byref(opt))
+    assert opt.seed_shift == 0 and list(opt.reserved) == [0, 0, 0]
+    opt.seed_shift = 2
+    assert L.ws_options_validate(ctypes.byref(opt)) == pkg._ffi.WS_ERR_BAD_ARG
+    opt.seed_shift = 1
+    assert L.ws_options_validate(ctypes.byref(opt)) == 0
+    opt.reserved[1] = 7
+    assert L.ws_options_validate(ctypes.byref(opt)) == pkg._ffi.WS_ERR_BAD_ARG
+
+
+def test_shipped_library_ignores_its_environment(pkg):
+    # debug / A-B knobs (WS_DEBUG_MAXIT, WS_NO_GRAPH ...) exist only in a -DWS_TUNING build: the product .so must not
+    # even contain their names, let alone read them
+    blob = open(pkg._ffi.LIB_PATH, "rb").read()
+    for knob in (b"WS_DEBUG_MAXIT", b"WS_NO_GRAPH", b"WS_NO_SPECULATION", b"WS_NO_SEED_TABLES", b"WS_NO_BATCH_STACK",
+                 b"WS_BATCH_MAX_PX", b"WS_RELAX_P0_ROUNDS", b"WS_RELAX_CHUNK_FROM", b"WS_PAINT_STEPS"):
+        assert knob not in blob, knob
+    for src in ("ws_api.hip", "ws_kernels.hip", "ws_relax.hip", "ws_merge.hip", "ws_preproc.hip"):
+        text = open(os.path.join(ROOT, "rustronomy-watershed_amd", "csrc", src)).read()
+        assert "getenv" not in text.replace("tuning_env", ""), src
 
 
 def test_builder_mirrors_reference(pkg):
@@ -129,3 +151,13 @@ def test_integration_extern_block_lists_every_header_function():
     assert len(names) >= 25
     missing = [n for n in names if f"fn {n}(" not in doc]
     assert not missing, missing
+    # the Rust shim's extern block (rust/src/hip_ffi.rs) declares every one of them, with the ABI version of the header
+    ffi = open(os.path.join(root, "rust", "src", "hip_ffi.rs")).read()
+    missing = [n for n in names if f"pub fn {n}(" not in ffi]
+    assert not missing, missing
+    version = re.search(r"#define WS_ABI_VERSION (\d+)", header).group(1)
+    assert f"WS_ABI_VERSION: c_int = {version};" in ffi
+    shim = open(os.path.join(root, "rust", "src", "watershed_hip.rs")).read()
+    for method in ("fn transform(", "fn transform_with_hook(", "fn transform_to_list(", "fn transform_history(",
+                   "fn find_local_minima(", "fn pre_processor_with_max<", "fn build_segmenting(", "fn build_merging("):
+        assert method in shim, method

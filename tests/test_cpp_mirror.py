@@ -39,3 +39,4 @@ def test_cpp_mirror_gpu():
     out = subprocess.run([_build(), "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu checks ok" in out.stdout
+    assert "shim sequence ok" in out.stdout          # the Rust shim's ABI call order, executed from C++

@@ -474,15 +474,19 @@ def test_graph_replay_of_repeated_transforms(pkg):
         assert eng.stats()["graph_launches"] == 1
 
 
-def test_segment_batch_in_several_groups(pkg, monkeypatch):
-    # a stack may hold at most 2^31 pixels; larger batches are cut into groups.  WS_BATCH_MAX_PX lowers the limit so
-    # that a small batch exercises the grouping (3 + 3 + 1 slices, the last group a single slice)
+def test_segment_batch_in_several_groups(pkg):
+    # a stack may hold at most 2^31 pixels; larger batches are cut into groups.  ws_ctx_set_batch_pixel_limit lowers the
+    # limit so that a small batch exercises the grouping (3 + 3 + 1 slices, the last group a single slice)
     import importlib
     dev = importlib.import_module("rustronomy_watershed_amd.device")
     eng = dev.DeviceEngine(0)
     himgs, hseeds = _batch_case(7, 32, 64, 4100)
-    monkeypatch.setenv("WS_BATCH_MAX_PX", str(3 * 32 * 64))
+    eng.ctx.set_batch_pixel_limit(3 * 32 * 64)
     got = _run_batch(eng, himgs, hseeds)
+    for k in range(7):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+    eng.ctx.set_batch_pixel_limit(0)
+    got = _run_batch(eng, himgs, hseeds)          # one stack again
     for k in range(7):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
 
