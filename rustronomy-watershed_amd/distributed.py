@@ -24,7 +24,12 @@ def shard_slices(n_slices, rank, world):
 
 
 def row_block(height, rank, world):
-    """(r0, r1, lo, hi): owned global rows [r0, r1) and local-plane rows [lo, hi) including halos."""
+    """(r0, r1, lo, hi): owned global rows [r0, r1) and local-plane rows [lo, hi) including halos.
+    Every rank must own at least one row: a rank without rows would hand a halo row on as if it were its own."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} of {world}")
+    if height < world:
+        raise ValueError(f"a field of {height} rows cannot be split into {world} row blocks: use at most {height} ranks")
     base, extra = divmod(height, world)
     r0 = rank * base + min(rank, extra)
     r1 = r0 + base + (1 if rank < extra else 0)
