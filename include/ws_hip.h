@@ -263,6 +263,28 @@ int ws_block_relax(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t
                    uint8_t max_water_level, uint32_t *d_keys, int *changed);
 int ws_block_resolve(ws_ctx *ctx, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w, int *changed);
 
+/* The same block in its fast form, for seed lists in strictly increasing row-major order (what ws_find_local_minima
+ * returns): a rank's seeds -- those on any of its local rows, halo rows included -- are then entries [g0, g0 + n) of the
+ * caller's list, in local coordinates, and first_colour = g0 + 1.  Needs w % 4 == 0 and h * w < 2^31; anything else
+ * (WS_ERR_UNSUPPORTED) goes through ws_block_init / _relax / _resolve above.  Sequence on every rank (distributed.py):
+ *   ws_block_begin;  repeat { swap halo rows of d_keys with the neighbours; stop when no rank received a row that
+ *   differs from what it held; ws_block_relax_halo };  ws_block_resolve_local;  ws_block_export_boundary;  all-gather the
+ *   2 * w words of every rank into one table;  ws_block_import_boundary.
+ * Stamps need that iteration (a flood may cross a seam more than once); labels do not: after the local resolve every
+ * label is a colour or a reference to a neighbour's boundary-row pixel, the boundary rows of all ranks form a closed
+ * table (entry (rank r, side s, column x) at (2 r + s) * w + x; s = 0 first own row, 1 last own row; a reference is
+ * 0x80000000 | entry index), and every rank resolves the gathered table for itself. */
+int ws_block_begin(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride, uint8_t max_water_level,
+                   const uint32_t *d_seeds_rc, size_t n_seeds, uint32_t first_colour, uint32_t *d_keys);
+int ws_block_relax_halo(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride, uint8_t max_water_level,
+                        int halo_top, int halo_bottom, uint32_t *d_keys);
+int ws_block_resolve_local(ws_ctx *ctx, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w, int halo_top,
+                           int halo_bottom);
+int ws_block_export_boundary(ws_ctx *ctx, const uint32_t *d_labels, size_t h, size_t w, int halo_top, int halo_bottom,
+                             size_t rank, uint32_t *d_rows /* 2 * w words */);
+int ws_block_import_boundary(ws_ctx *ctx, const uint32_t *d_table /* world * 2 * w words */, size_t world, size_t rank,
+                             uint32_t *d_labels, size_t h, size_t w, int halo_top, int halo_bottom);
+
 /* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
 int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                            uint64_t seed);

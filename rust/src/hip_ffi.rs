@@ -141,4 +141,15 @@ extern "C" {
         max_water_level: u8, d_keys: *mut u32, changed: *mut c_int) -> c_int;
     pub fn ws_block_resolve(ctx: *mut ws_ctx, d_keys: *const u32, d_labels: *mut u32, h: usize, w: usize,
         changed: *mut c_int) -> c_int;
+    // ... fast form for strictly increasing seed lists: one table exchange for the labels instead of rounds
+    pub fn ws_block_begin(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize, max_water_level: u8,
+        d_seeds_rc: *const u32, n_seeds: usize, first_colour: u32, d_keys: *mut u32) -> c_int;
+    pub fn ws_block_relax_halo(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        max_water_level: u8, halo_top: c_int, halo_bottom: c_int, d_keys: *mut u32) -> c_int;
+    pub fn ws_block_resolve_local(ctx: *mut ws_ctx, d_keys: *const u32, d_labels: *mut u32, h: usize, w: usize,
+        halo_top: c_int, halo_bottom: c_int) -> c_int;
+    pub fn ws_block_export_boundary(ctx: *mut ws_ctx, d_labels: *const u32, h: usize, w: usize, halo_top: c_int,
+        halo_bottom: c_int, rank: usize, d_rows: *mut u32) -> c_int;
+    pub fn ws_block_import_boundary(ctx: *mut ws_ctx, d_table: *const u32, world: usize, rank: usize, d_labels: *mut u32,
+        h: usize, w: usize, halo_top: c_int, halo_bottom: c_int) -> c_int;
 }

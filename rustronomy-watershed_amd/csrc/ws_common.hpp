@@ -84,7 +84,8 @@ hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int p
                         uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b);
 hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
-                       const uint32_t *slice_first = nullptr, size_t slice_px = 0);     // stack of slices: colours restart in every slice
+                       const uint32_t *slice_first = nullptr, size_t slice_px = 0,      // stack of slices: colours restart in every slice
+                       uint32_t colour_bias = 0);                                       // row block of a larger field: colour of list entry 0, minus 1
 // seeds of a stack of slices -> seeds of the stacked plane (row + slice * slice_h); slice_first: n_slices + 1 list offsets
 hipError_t stack_seeds(hipStream_t s, const uint32_t *seeds_rc, size_t n, const uint32_t *slice_first, size_t n_slices,
                        int slice_h, int pw, uint32_t *stacked_rc, uint32_t shift = 0);
@@ -118,7 +119,15 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
                               const uint32_t *gate = nullptr,     // speculative launch: a pass's convergence slot; both kernels leave if it is set
                               int slice_h = 0,                    // > 0: stack of independent slices (see relax_pass)
                               uint32_t *carry_flag = nullptr,     // set when a stamp carried out of its ring field (relax_pass with fresh_keys leaves the test to this kernel)
-                              const uint32_t *seed_err = nullptr);   // seed_tables()' three error words: both kernels leave when the tables are invalid
+                              const uint32_t *seed_err = nullptr,    // seed_tables()' three error words: both kernels leave when the tables are invalid
+                              int halo_flags = 0);                   // row block: bit 0 / 1 = the first / last row is a neighbour's (chains stop there)
+hipError_t resolve_chase_again(hipStream_t s, uint32_t *labels, int h, int w, uint32_t *ref_scratch);
+
+// row blocks of one field tiled over ranks (ws_block.hip)
+hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w, uint32_t pass, int halo_flags);
+hipError_t block_export_boundary(hipStream_t s, const uint32_t *labels, int h, int w, int halo_flags, uint32_t rank, uint32_t *rows);
+hipError_t block_import_boundary(hipStream_t s, const uint32_t *table, uint32_t world, uint32_t rank, uint32_t *resolved,
+                                 uint32_t *labels, int h, int w, int halo_flags);
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded = false);

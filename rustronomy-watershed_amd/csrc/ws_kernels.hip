@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
                                                                  uint32_t *mask, uint32_t *word_base, size_t npx, size_t nchunk,
                                                                  uint32_t *flags,
                                                                  uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
-                                                                 const uint32_t *__restrict__ slice_first, size_t slice_px) {
+                                                                 const uint32_t *__restrict__ slice_first, size_t slice_px, uint32_t colour_bias) {
   __shared__ __attribute__((aligned(16))) uint32_t sRow[PAINT_WAVES][TAB_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint2 *seeds = reinterpret_cast<const uint2 *>(seeds_rc);
@@ -343,6 +343,8 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
     const uint32_t sf = slice_first[min((size_t)((p0 + 128ull * (unsigned)lane) / slice_px), npx_slices)];
     b0 = b0 >= sf ? b0 - sf : 0u;
   }
+  // a row block of a larger field: its seeds are entries [g0, g0 + n) of the caller's list, so colours start at g0 + 1
+  b0 += colour_bias;
   const u32x4_z bases = u32x4_z{b0, b0 + c0, b0 + c0 + c1, b0 + c0 + c1 + c2};
   const size_t wi = (size_t)(p0 >> 5) + 4 * lane, nwords = (npx + 31) / 32;
   if (wi + 4 <= nwords && ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(word_base)) & 15u) == 0) {
@@ -388,13 +390,13 @@ hipError_t paint_labels(hipStream_t s, const uint32_t *seeds_rc, size_t n, int p
 // increasing") back and, if it is raised, repeats the transform with paint_labels.
 hipError_t seed_tables(hipStream_t s, const uint32_t *seeds_rc, size_t n, int ph, int pw, uint32_t *mask, uint32_t *word_base,
                        uint32_t *err_flag, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b,
-                       const uint32_t *slice_first, size_t slice_px) {
+                       const uint32_t *slice_first, size_t slice_px, uint32_t colour_bias) {
   const size_t npx = (size_t)ph * pw;
   const size_t per_wave = (size_t)TAB_WORDS * 32;
   const size_t nchunk = (npx + per_wave - 1) / per_wave;
   const size_t blocks = std::max<size_t>((nchunk + PAINT_WAVES - 1) / PAINT_WAVES, 1);
   k_seed_tables<<<(unsigned)blocks, 64 * PAINT_WAVES, 0, s>>>(seeds_rc, n, ph, pw, mask, word_base, npx, nchunk, err_flag,
-                                                             zero_a, n_zero_a, zero_b, n_zero_b, slice_first, slice_px);
+                                                             zero_a, n_zero_a, zero_b, n_zero_b, slice_first, slice_px, colour_bias);
   return hipGetLastError();
 }
 
@@ -701,14 +703,18 @@ static_assert(RL_ROWS * RL_P <= (int)RL_HALO, "cell indices must stay below the 
 // a colour of the tile that is not a reference (0: not one lake; RL_TILE_UNDECIDED: one lake, but every pixel's
 // chain leaves the tile, k_tile_scan looks at the finished labels).  Saves a 268 MB pass over the label plane.
 constexpr uint32_t RL_TILE_UNDECIDED = 0xFFFFFFFFu;
-template <bool TABLES, bool MERGE>
+// BLOCK: the plane is a row block of a larger field (ws_block_*): its first / last row (halo_flags bit 0 / 1) is a halo
+// copy of a neighbour rank's row.  A halo pixel that some flood reached (finite, non-zero stamp) has a colour only its
+// owner knows: here it stands for itself as a REFERENCE, so every chain that ends on it is left as a reference to it
+// (k_resolve_chase stops at halo pixels) until ws_block_import_boundary has written the halo rows' true colours.
+template <bool TABLES, bool MERGE, bool BLOCK>
 __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *__restrict__ keys, uint32_t *labels,
                                                             int H, int W, int tilesX, uint32_t *ref_count,
                                                             uint32_t *ref_list, uint32_t max_rounds,
                                                             const uint32_t *__restrict__ seed_mask,
                                                             const uint32_t *__restrict__ word_base, uint32_t *tile_min,
                                                             const uint32_t *__restrict__ gate, int SH, uint32_t *carry_flag,
-                                                            const uint32_t *__restrict__ seed_err) {
+                                                            const uint32_t *__restrict__ seed_err, int halo_flags) {
   // One LDS tile, used three times: stamps (+ halo ring) -> parent pointers -> painted colours.
   __shared__ __attribute__((aligned(16))) uint32_t sB[RL_ROWS * RL_P];
   // Side tables built from a seed list that turned out not to be strictly increasing, or to leave the plane, describe
@@ -901,6 +907,16 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       }
     }
   }
+  if (BLOCK && TABLES) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gy = gy0 + r;
+      const bool halo_row = (gy == 0 && (halo_flags & 1)) || (gy == H - 1 && (halo_flags & 2));
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (halo_row && gx0 + c < W && K[r][c] != 0u && K[r][c] != KEY_INF) Lb[r][c] = REF_BIT | (uint32_t)((size_t)gy * W + gx0 + c);
+    }
+  }
   // every pointer is final and in registers: the tile now becomes COLOURS -- a pixel's own colour (a seed's, or
   // none), and in the halo ring a REFERENCE to the global pixel the cell stands for -- so that whatever a
   // pointer ends at, the answer is one unconditional LDS read of its target: no decode of the cell index, no
@@ -1010,7 +1026,10 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 // resolves to.
 __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
-                                const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err) {
+                                const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err,
+                                size_t follow_from, size_t follow_to) {
+  // [follow_from, follow_to): the pixels a chain may be followed THROUGH -- the whole plane [0, n), or, for a row block
+  // whose halo rows still hold references to themselves, the plane without those rows: a chain stops at a halo pixel.
   const int lane = threadIdx.x & 63;
   if (seed_err && (seed_err[0] | seed_err[2]) != 0u) return;      // invalid side tables: k_resolve_local wrote no lists (see there)
   if (gate && __builtin_amdgcn_ballot_w64(gate[lane * STRIPE_STRIDE] != 0u) != 0ull) return;      // see k_resolve_local
@@ -1024,7 +1043,7 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
       // A reference points at a pixel with a strictly smaller stamp, so a chain visits a pixel at most once: fewer than n
       // hops.  The range test and the hop bound are belt and braces: with invalid side tables (the only source of words
       // that are not colours or references of this plane) both resolve kernels have already left.
-      for (size_t hops = 0; (v & REF_BIT) && (v & ~REF_BIT) < n && hops < n; ++hops)
+      for (size_t hops = 0; (v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < follow_to - follow_from && hops < n; ++hops)
         v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       labels[e.x] = v;
     }
@@ -1039,25 +1058,39 @@ size_t resolve_ref_capacity(int h, int w) {
 
 hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *labels, int h, int w, uint32_t *ref_scratch,
                               uint32_t max_rounds, const uint32_t *seed_mask, const uint32_t *word_base, uint32_t *tile_min,
-                              const uint32_t *gate, int slice_h, uint32_t *carry_flag, const uint32_t *seed_err) {
+                              const uint32_t *gate, int slice_h, uint32_t *carry_flag, const uint32_t *seed_err, int halo_flags) {
   const int tx = tiles_of(w), ty = tiles_of(h);
   const int sh = slice_h > 0 ? slice_h : h;
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
-  if (seed_mask && tile_min)
-    k_resolve_local<true, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag, seed_err);
+  if (seed_mask && halo_flags)
+    k_resolve_local<true, false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag, seed_err, halo_flags);
+  else if (seed_mask && tile_min)
+    k_resolve_local<true, true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag, seed_err, 0);
   else if (seed_mask)
-    k_resolve_local<true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag, seed_err);
+    k_resolve_local<true, false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag, seed_err, 0);
   else if (tile_min)
-    k_resolve_local<false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh, carry_flag, nullptr);
+    k_resolve_local<false, true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, tile_min, gate, sh, carry_flag, nullptr, 0);
   else
-    k_resolve_local<false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag, nullptr);
+    k_resolve_local<false, false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag, nullptr, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr);
+  const size_t from = (halo_flags & 1) ? (size_t)w : 0, to = (halo_flags & 2) ? n - (size_t)w : n;
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to);
+  return hipGetLastError();
+}
+
+// the chase alone, over the lists the last resolve_two_launch left in ref_scratch: every chain is followed to its end
+// (a row block after ws_block_import_boundary has put the neighbours' colours into its halo rows)
+hipError_t resolve_chase_again(hipStream_t s, uint32_t *labels, int h, int w, uint32_t *ref_scratch) {
+  const size_t n = (size_t)h * w;
+  if (n == 0) return hipSuccess;
+  const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
+  const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n);
   return hipGetLastError();
 }
 

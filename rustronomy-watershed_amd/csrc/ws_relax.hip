@@ -622,6 +622,26 @@ size_t relax_tiles(int h, int w) {
   return (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
 }
 
+// Row block of a tiled field: the caller has rewritten the plane's halo rows (row 0 and / or row h - 1).  Only tiles that
+// hold those rows have anything new to look at: raise, in the stamp array that the EVEN pass `pass` reads (the shifted
+// grid's), every quadrant flag of its first / last tile row, so that exactly the first / last tile row of the anchored
+// grid runs in that pass; what they change spreads by the usual flags.  The stamp arrays must be zeroed first.
+__global__ void k_flag_tile_rows(uint32_t *prev, int sx, int sy, uint32_t pass, int halo_flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sx * 4) return;
+  if (halo_flags & 1) prev[i] = pass;
+  if (halo_flags & 2) prev[(size_t)(sy - 1) * sx * 4 + i] = pass;
+}
+
+hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w, uint32_t pass, int halo_flags) {
+  if ((pass & 1u) != 0 || h == 0 || w == 0) return hipErrorInvalidValue;
+  const int th = RX_NW * RX_P;
+  const int sx = (w + RX_TW - 1) / RX_TW + 1, sy = (h + th - 1) / th + 1;
+  const size_t cap = (size_t)sx * sy * 4;
+  k_flag_tile_rows<<<(sx * 4 + 255) / 256, 256, 0, s>>>(stamps + cap, sx, sy, pass, halo_flags);      // array 1: written by odd passes
+  return hipGetLastError();
+}
+
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded) {

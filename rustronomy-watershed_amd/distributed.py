@@ -2,13 +2,22 @@
 xGMI on GPUs; "gloo" for CPU rehearsal).
 
 * Independent slices (BASELINE config C4) shard with NO collective on the data path:
-  `shard_slices` assigns slice i to rank i % world, each rank runs its own transforms.
+  `shard_slices` assigns slice i to rank i % world, each rank runs its own (stacked) transforms.
 * One field tiled over ranks (config C5): row blocks with a 1-row halo.  The flood is the unique
   fixpoint of the arrival-stamp recurrence, so the tiled run is bit-exact with
-  the single-domain run: every rank relaxes its block to local convergence, neighbours swap halo
-  rows, a 1-word all-reduce says whether anyone changed; repeat until quiet, then the same loop for
-  the labels.  Messages are one image row of u32 (128 KiB at 32768 columns): latency-bound, so the
-  exchange count (a handful, not ~2000 as in a per-ring sweep) is what matters on xGMI.
+  the single-domain run.
+    - Stamps: every rank relaxes its block to local convergence with the single-GPU kernels (seed side
+      tables, fused passes), neighbours swap halo rows, and a 1-word all-reduce says whether any rank
+      RECEIVED a row that differs from the one it held; if so the ranks re-relax from the tile rows that
+      hold the halo rows (`ws_block_relax_halo`) and swap again.  A flood crosses a seam a handful of
+      times at most, so this is 2-4 exchanges, not one per flood ring.  One host read per exchange.
+    - Labels: no rounds at all.  After the local two-launch resolve every label is a colour or a
+      reference to a neighbour's boundary-row pixel; the boundary rows of all ranks form a closed table
+      (2 x width words per rank), all-gathered once, resolved by every rank for itself
+      (`ws_block_export_boundary` / `ws_block_import_boundary`, csrc/ws_block.hip).
+  Seed lists that are not strictly increasing, or widths with w % 4 != 0, take the general form
+  (`ws_block_init` / `_relax` / `_resolve`: painted seeds, iterative label rounds), chosen by all ranks
+  together.  Messages are image rows of u32 (128 KiB at 32768 columns): latency-bound on xGMI.
 """
 import ctypes
 
@@ -57,29 +66,81 @@ class HipBlockEngine:
         assert self.img.is_cuda and self.img.dtype == torch.uint8
         self.h, self.w = self.img.shape
         dev = self.img.device
-        self.seeds = seeds_local.to(dev)
-        self.colours = colours.to(dev)
+        self.seeds = seeds_local.to(dev).contiguous()
+        self.colours = colours.to(dev).contiguous()
         self.max_level = max_level
         self.keys = torch.empty((self.h, self.w), dtype=torch.int32, device=dev)
         self.labels = torch.empty((self.h, self.w), dtype=torch.int32, device=dev)
+        self.halo_top = self.halo_bot = False
+        n = int(self.seeds.shape[0])
+        # the fast form wants the rank's seeds to be one contiguous, strictly increasing range of the caller's list (the
+        # order is checked by ws_block_begin on the device; that the colours count up by one, here)
+        consecutive = n < 2 or bool((self.colours[1:] - self.colours[:-1] == 1).all().item())
+        self.first_colour = int(self.colours[0].item()) if n else 1
+        self.fast = consecutive and self.w % 4 == 0 and self.h >= 2 and self.h * self.w < 2 ** 31
 
+    def set_halos(self, top, bottom):
+        self.halo_top, self.halo_bot = bool(top), bool(bottom)
+
+    def _check(self, rc):
+        self.eng.ctx.check(rc)
+
+    # ---- fast form -------------------------------------------------------------------------------------------------
+    def try_begin(self):
+        """Seed tables + relaxation to local convergence.  False: this block needs the general form."""
+        if not self.fast:
+            return False
+        n = int(self.seeds.shape[0])
+        rc = _ffi.lib().ws_block_begin(self.eng.ctx.handle, self.img.data_ptr(), self.h, self.w, self.w, self.max_level,
+                                       self.seeds.data_ptr() if n else None, n, self.first_colour, self.keys.data_ptr())
+        if rc == _ffi.WS_ERR_UNSUPPORTED:
+            self.fast = False
+            return False
+        self._check(rc)
+        return True
+
+    def relax_halo(self):
+        self._check(_ffi.lib().ws_block_relax_halo(self.eng.ctx.handle, self.img.data_ptr(), self.h, self.w, self.w, self.max_level,
+                                                   int(self.halo_top), int(self.halo_bot), self.keys.data_ptr()))
+
+    def resolve_local(self):
+        self._check(_ffi.lib().ws_block_resolve_local(self.eng.ctx.handle, self.keys.data_ptr(), self.labels.data_ptr(), self.h, self.w,
+                                                      int(self.halo_top), int(self.halo_bot)))
+
+    def export_boundary(self, rank):
+        rows = torch.empty((2, self.w), dtype=torch.int32, device=self.img.device)
+        self._check(_ffi.lib().ws_block_export_boundary(self.eng.ctx.handle, self.labels.data_ptr(), self.h, self.w,
+                                                        int(self.halo_top), int(self.halo_bot), rank, rows.data_ptr()))
+        return rows
+
+    def import_boundary(self, table, rank, world):
+        table = table.to(self.img.device).contiguous()
+        assert table.numel() == world * 2 * self.w and table.dtype == torch.int32
+        self._check(_ffi.lib().ws_block_import_boundary(self.eng.ctx.handle, table.data_ptr(), world, rank, self.labels.data_ptr(),
+                                                        self.h, self.w, int(self.halo_top), int(self.halo_bot)))
+
+    def single(self):
+        """world == 1: the block is the whole field -- the ordinary single-device transform."""
+        return self.eng.segment(self.img, self.seeds, max_level=self.max_level, out=self.labels)
+
+    # ---- general form (any seed list, any width) -------------------------------------------------------------------
     def init(self):
         n = int(self.seeds.shape[0])
-        self.eng.ctx.check(_ffi.lib().ws_block_init(self.eng.ctx.handle, self.h, self.w,
-                                                    self.seeds.data_ptr() if n else None,
-                                                    self.colours.data_ptr() if n else None, n,
-                                                    self.keys.data_ptr(), self.labels.data_ptr()))
+        self._check(_ffi.lib().ws_block_init(self.eng.ctx.handle, self.h, self.w,
+                                             self.seeds.data_ptr() if n else None,
+                                             self.colours.data_ptr() if n else None, n,
+                                             self.keys.data_ptr(), self.labels.data_ptr()))
 
     def relax(self):
         ch = ctypes.c_int(0)
-        self.eng.ctx.check(_ffi.lib().ws_block_relax(self.eng.ctx.handle, self.img.data_ptr(), self.h, self.w, self.w,
-                                                     self.max_level, self.keys.data_ptr(), ctypes.byref(ch)))
+        self._check(_ffi.lib().ws_block_relax(self.eng.ctx.handle, self.img.data_ptr(), self.h, self.w, self.w,
+                                              self.max_level, self.keys.data_ptr(), ctypes.byref(ch)))
         return bool(ch.value)
 
     def resolve(self):
         ch = ctypes.c_int(0)
-        self.eng.ctx.check(_ffi.lib().ws_block_resolve(self.eng.ctx.handle, self.keys.data_ptr(), self.labels.data_ptr(),
-                                                       self.h, self.w, ctypes.byref(ch)))
+        self._check(_ffi.lib().ws_block_resolve(self.eng.ctx.handle, self.keys.data_ptr(), self.labels.data_ptr(),
+                                                self.h, self.w, ctypes.byref(ch)))
         return bool(ch.value)
 
 
@@ -88,11 +149,11 @@ def _comm_device(plane):
     return plane.device if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def exchange_halos(plane, rank, world, group=None):
-    """Swap halo rows with the neighbour ranks.  `plane` is the local (h, w) tensor whose first row
-    is a halo iff rank > 0 and whose last row is a halo iff rank < world - 1."""
+def swap_halo_rows(plane, rank, world, group=None):
+    """Sends the first / last OWNED row to the upper / lower neighbour and receives their boundary rows.
+    Returns [(halo row index, received row on plane.device)]; the plane is not written."""
     if world == 1:
-        return
+        return []
     dev = _comm_device(plane)
     ops, recvs = [], []
     if rank > 0:                      # upper neighbour: send my first owned row, receive my top halo
@@ -107,20 +168,49 @@ def exchange_halos(plane, rank, world, group=None):
         recvs.append((plane.shape[0] - 1, recv))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
-    for row, recv in recvs:
+    return [(row, recv.to(plane.device)) for row, recv in recvs]
+
+
+def exchange_halos(plane, rank, world, group=None):
+    """Swap halo rows with the neighbour ranks, in place.  `plane` is the local (h, w) tensor whose first row
+    is a halo iff rank > 0 and whose last row is a halo iff rank < world - 1."""
+    for row, recv in swap_halo_rows(plane, rank, world, group):
         plane[row].copy_(recv)
 
 
-def _any_rank(flag, like, group=None):
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_comm_device(like))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+def _reduce_flag(flag, like, op, group=None):
+    """One-word all-reduce of a Python bool or a 0-d / 1-element tensor; ONE host read."""
+    if isinstance(flag, torch.Tensor):
+        t = flag.to(torch.int32).reshape(1).to(_comm_device(like))
+    else:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_comm_device(like))
+    dist.all_reduce(t, op=op, group=group)
     return bool(t.item())
 
 
-def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
-    """Segmenting transform of one field tiled over `world` ranks.  `block` is this rank's engine
-    (HipBlockEngine, or any object with init/relax/resolve and .keys/.labels planes).
-    Returns (owned label rows, exchange rounds)."""
+def _any_rank(flag, like, group=None):
+    return _reduce_flag(flag, like, dist.ReduceOp.MAX, group)
+
+
+def _all_ranks(flag, like, group=None):
+    return _reduce_flag(flag, like, dist.ReduceOp.MIN, group)
+
+
+def _gather_rows(rows, world, group=None):
+    """(2, w) per rank -> (world, 2, w) on every rank."""
+    dev = _comm_device(rows)
+    mine = rows.to(dev).contiguous()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        return out
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.stack(parts)
+
+
+def _segment_tiled_general(block, rank, world, group, max_rounds):
+    """Any seed list: painted seeds, iterative relaxation AND iterative label rounds (one halo swap + one flag each)."""
     block.init()
     rounds = 0
     for plane_name, step in (("keys", block.relax), ("labels", block.resolve)):
@@ -128,8 +218,39 @@ def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
             changed = step()
             exchange_halos(getattr(block, plane_name), rank, world, group)
             rounds += 1
-            if world == 1 or not _any_rank(changed, getattr(block, plane_name), group):
+            if not _any_rank(changed, getattr(block, plane_name), group):
                 break
+    return rounds
+
+
+def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
+    """Segmenting transform of one field tiled over `world` ranks.  `block` is this rank's engine
+    (HipBlockEngine, or any object with the same steps and .keys / .labels planes).
+    Returns (owned label rows, number of collective exchanges)."""
+    if world == 1:
+        return block.single(), 0
+    block.set_halos(rank > 0, rank < world - 1)
+    fast = block.try_begin()
+    if not _all_ranks(fast, block.keys, group):          # decided together: the two forms exchange different things
+        rounds = 1 + _segment_tiled_general(block, rank, world, group, max_rounds)
+    else:
+        rounds = 1
+        for _ in range(max_rounds):
+            got = swap_halo_rows(block.keys, rank, world, group)
+            rounds += 1
+            new = None
+            for row, recv in got:
+                d = (recv != block.keys[row]).any()
+                new = d if new is None else (new | d)
+            if not _any_rank(new if new is not None else False, block.keys, group):
+                break                                      # every halo row already equals its neighbour's boundary row
+            for row, recv in got:
+                block.keys[row].copy_(recv)
+            block.relax_halo()
+        block.resolve_local()
+        table = _gather_rows(block.export_boundary(rank), world, group)
+        block.import_boundary(table.reshape(-1), rank, world)
+        rounds += 1
     top = 1 if rank > 0 else 0
     bot = block.labels.shape[0] - (1 if rank < world - 1 else 0)
     return block.labels[top:bot], rounds

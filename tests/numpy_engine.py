@@ -1,11 +1,13 @@
-"""CPU stand-in for HipBlockEngine (TEST INFRASTRUCTURE): the same init / relax / resolve steps of a
-row block, in vectorised numpy, so the multi-rank orchestration in
+"""CPU stand-in for HipBlockEngine (TEST INFRASTRUCTURE): the same steps of a row block -- both the general form
+(init / relax / resolve) and the fast form (try_begin / relax_halo / resolve_local / export_boundary /
+import_boundary) -- in vectorised numpy, so the multi-rank orchestration in
 rustronomy-watershed_amd/distributed.py can be rehearsed with the gloo backend where there is no GPU.
-Follows include/ws_hip.h "row blocks" and DESIGN.md section 2; never used by the product."""
+Follows include/ws_hip.h "row blocks", csrc/ws_block.hip and DESIGN.md section 2; never used by the product."""
 import numpy as np
 import torch
 
 INF = 0xFF000000
+REF = 0x80000000
 
 
 class NumpyBlockEngine:
@@ -17,6 +19,12 @@ class NumpyBlockEngine:
         self.max_level = max_level
         self.keys = torch.empty((self.h, self.w), dtype=torch.int32)
         self.labels = torch.empty((self.h, self.w), dtype=torch.int32)
+        self.halo_top = self.halo_bot = False
+        # the fast form needs a strictly increasing list whose colours count up by one (a contiguous range of the
+        # caller's list); `force_general` lets a test send a sorted list through the general form
+        lin = self.seeds[:, 0] * self.w + self.seeds[:, 1]
+        self.fast = bool((np.diff(lin) > 0).all() and (np.diff(self.colours) == 1).all())
+        self.force_general = False
 
     def _k(self):
         return self.keys.numpy().view(np.uint32)
@@ -76,3 +84,80 @@ class NumpyBlockEngine:
             l[upd] = src[upd].astype(np.uint32)
             changed = True
         return changed
+
+    # ---- fast form (ws_block_begin ... ws_block_import_boundary) -------------------------------------------------------
+    def set_halos(self, top, bottom):
+        self.halo_top, self.halo_bot = bool(top), bool(bottom)
+
+    def try_begin(self):
+        if not self.fast or self.force_general:
+            return False
+        self.init()
+        self.relax()
+        return True
+
+    def relax_halo(self):
+        self.relax()
+
+    def resolve_local(self):
+        """Labels of the block: a colour, 0, or REF | index of the halo pixel the parent chain ends on."""
+        k = self._k().astype(np.int64)
+        l = self._l()
+        big, _ = self._min4(k)
+        d, r, lf, u = big[2:, 1:-1], big[1:-1, 2:], big[1:-1, :-2], big[:-2, 1:-1]
+        inter = np.zeros((self.h, self.w), dtype=bool)
+        inter[1:-1, 1:-1] = True
+        has = (k != 0) & (k != INF) & inter
+        l[:] = 0
+        for (rr, cc), col in zip(self.seeds, self.colours):
+            l[rr, cc] = col
+        idx = np.arange(self.h * self.w, dtype=np.int64).reshape(self.h, self.w)
+        for row, on in ((0, self.halo_top), (self.h - 1, self.halo_bot)):
+            if on:                                     # a neighbour's pixel some flood reached: only its owner knows the colour
+                m = (k[row] != 0) & (k[row] != INF)
+                l[row, m] = (REF | idx[row, m]).astype(np.uint32)
+        while True:
+            lb = np.zeros((self.h + 2, self.w + 2), dtype=np.int64)
+            lb[1:-1, 1:-1] = l
+            src = np.where(d < k, lb[2:, 1:-1], np.where(r < k, lb[1:-1, 2:], np.where(lf < k, lb[1:-1, :-2], lb[:-2, 1:-1])))
+            upd = has & (l == 0) & (src != 0)
+            if not upd.any():
+                break
+            l[upd] = src[upd].astype(np.uint32)
+
+    def export_boundary(self, rank):
+        l = self._l()
+        rows = np.stack([l[1 if self.halo_top else 0], l[self.h - 2 if self.halo_bot else self.h - 1]]).astype(np.int64)
+        ref = (rows & REF) != 0
+        tgt = rows & (REF - 1)
+        r, c = tgt // self.w, tgt % self.w
+        up = ref & (r == 0) & self.halo_top
+        dn = ref & (r == self.h - 1) & self.halo_bot
+        assert (ref == (up | dn)).all()                # references only ever name halo pixels
+        rows[up] = REF | (((rank - 1) * 2 + 1) * self.w + c[up])
+        rows[dn] = REF | (((rank + 1) * 2 + 0) * self.w + c[dn])
+        return torch.from_numpy(rows.astype(np.uint32).view(np.int32))
+
+    def import_boundary(self, table, rank, world):
+        t = table.numpy().view(np.uint32).astype(np.int64).reshape(-1)
+        assert t.size == world * 2 * self.w
+        for _ in range(t.size + 1):                    # pointer jumping until every entry is a colour
+            ref = (t & REF) != 0
+            if not ref.any():
+                break
+            t[ref] = t[t[ref] & (REF - 1)]
+        l = self._l()
+        if self.halo_top:
+            l[0] = t[((rank - 1) * 2 + 1) * self.w:((rank - 1) * 2 + 2) * self.w]
+        if self.halo_bot:
+            l[self.h - 1] = t[((rank + 1) * 2) * self.w:((rank + 1) * 2 + 1) * self.w]
+        flat = l.reshape(-1)
+        ref = (flat & np.uint32(REF)) != 0
+        flat[ref] = flat[(flat[ref] & np.uint32(REF - 1)).astype(np.int64)]
+        assert not ((flat & np.uint32(REF)) != 0).any()
+
+    def single(self):
+        self.init()
+        self.relax()
+        self.resolve()
+        return self.labels

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _tiled_worker(rank, world, port, img, seeds, max_level, outdir):
+def _tiled_worker(rank, world, port, img, seeds, max_level, outdir, force_general=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +36,9 @@ def _tiled_worker(rank, world, port, img, seeds, max_level, outdir):
         r0, r1, lo, hi = wd.row_block(img.shape[0], rank, world)
         loc, col = wd.local_seeds(seeds.astype(np.int64), lo, hi)
         block = NumpyBlockEngine(img[lo:hi], loc.numpy(), col.numpy(), max_level)
+        block.force_general = force_general and rank == world - 1      # ONE rank that cannot: every rank must follow
         owned, rounds = wd.segment_tiled(block, rank, world)
+        np.save(os.path.join(outdir, f"fast{rank}.npy"), np.array([block.fast and not block.force_general]))
         assert owned.shape[0] == r1 - r0
         np.save(os.path.join(outdir, f"part{rank}.npy"), owned.numpy().view(np.uint32))
         np.save(os.path.join(outdir, f"rounds{rank}.npy"), np.array([rounds]))
@@ -44,9 +46,9 @@ def _tiled_worker(rank, world, port, img, seeds, max_level, outdir):
         dist.destroy_process_group()
 
 
-def _run_tiled(img, seeds, world, max_level=254):
+def _run_tiled(img, seeds, world, max_level=254, force_general=False):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_tiled_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), max_level, d),
+        mp.spawn(_tiled_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), max_level, d, force_general),
                  nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"part{r}.npy")) for r in range(world)]
         rounds = [int(np.load(os.path.join(d, f"rounds{r}.npy"))[0]) for r in range(world)]
@@ -60,7 +62,16 @@ def test_tiled_field_is_bit_exact_with_single_domain(world):
     seeds = ol.find_local_minima(img)
     got, rounds = _run_tiled(img, seeds, world)
     assert (got == ol.segment(img, seeds)).all()
-    assert rounds >= 4                               # at least one productive + one quiet round per phase
+    assert 3 <= rounds <= 8                          # form vote + stamp exchanges (a handful) + ONE table exchange for the labels
+    # the general form (one rank cannot use the fast one, so all ranks take it): stamp rounds AND label rounds
+    got, rounds_general = _run_tiled(img, seeds, world, force_general=True)
+    assert (got == ol.segment(img, seeds)).all()
+    assert rounds_general >= 5
+    # a seed list that is not sorted: no rank can use the fast form
+    rng = np.random.default_rng(world)
+    shuffled = seeds[rng.permutation(len(seeds))]
+    got, _ = _run_tiled(img, shuffled, world)
+    assert (got == ol.segment(img, shuffled)).all()
 
 
 def test_tiled_field_long_paths_cross_the_seam_many_times():
@@ -73,7 +84,10 @@ def test_tiled_field_long_paths_cross_the_seam_many_times():
     want = ol.segment(img, seeds)
     got, rounds = _run_tiled(img, seeds, 2)
     assert (got == want).all()
-    assert rounds > 10
+    assert rounds > 10                               # the stamps need a round per crossing ...
+    got, rounds_general = _run_tiled(img, seeds, 2, force_general=True)
+    assert (got == want).all()
+    assert rounds_general > rounds + 5               # ... the labels only in the general form: the table exchange is one
 
 
 def test_tiled_field_seeds_on_halo_rows_and_low_max_level():
@@ -83,6 +97,19 @@ def test_tiled_field_seeds_on_halo_rows_and_low_max_level():
     for maxlvl in (60, 254):
         got, _ = _run_tiled(img, seeds, 2, max_level=maxlvl)
         assert (got == ol.segment(img, seeds, max_level=maxlvl)).all()
+
+
+def test_tiled_field_more_ranks_than_a_chain_is_long():
+    # world 4 on a smooth field: label chains run through several blocks (a boundary-table entry that refers to an
+    # entry of the next rank, which refers on), blocks of 8-9 rows
+    img = cases.smooth_field(34, 44, 9)
+    seeds = ol.find_local_minima(img)[::3]
+    got, _ = _run_tiled(img, seeds, 4)
+    assert (got == ol.segment(img, seeds)).all()
+    with pytest.raises(Exception):
+        ge.load_package()
+        import importlib
+        importlib.import_module("rustronomy_watershed_amd.distributed").row_block(3, 0, 4)      # fewer rows than ranks
 
 
 def test_row_blocks_and_slice_sharding_partition_exactly():
