@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libws_hip.so")
+# WS_HIP_LIB: another build of the same ABI (tools/ point it at the -DWS_TUNING build for their A/B experiments)
+LIB_PATH = os.environ.get("WS_HIP_LIB") or os.path.join(_HERE, "libws_hip.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)

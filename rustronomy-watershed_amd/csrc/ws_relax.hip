@@ -165,8 +165,11 @@ __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, 
 // the value that enters it from its neighbour.  Used only from pass RX_SCAN_FROM_PASS on (the bench field
 // has converged by then; the scan costs registers, so the early passes run a variant without it) and
 // only for tiles that are still moving after RX_SCAN_AFTER rounds.
-constexpr uint32_t RX_SCAN_AFTER = 2;
+// (r2: scans from the first round on and at most two rounds per tile run in those passes -- 8192^2 smooth maps, correlation
+// length 16 / 64 / 256 px: 16.4 -> 13.1, 29.2 -> 22.2, 12.5 -> 10.7 ms; same passes, shorter ones: gpurun_out/r2e)
+constexpr uint32_t RX_SCAN_AFTER = 0;
 constexpr uint32_t RX_SCAN_FROM_PASS = 4;
+constexpr uint32_t RX_LATE_ROUND_CAP = 2;      // rounds per tile run from pass RX_SCAN_FROM_PASS on (0: no cap); see relax_pass
 
 template <bool TRACK, bool RIGHT>
 __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b)[RX_P], uint32_t halo_in, int lane, bool &changed) {
@@ -251,7 +254,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
-                                                      int pad) {
+                                                      int pad, uint32_t scan_after) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -481,7 +484,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
     sweep_cols<false, true>(T, B, up, dn, L, R, untracked);       // right
-    const bool long_range = SCAN && round > RX_SCAN_AFTER;        // workgroup uniform
+    const bool long_range = SCAN && round > scan_after;           // workgroup uniform
     if (long_range) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(halo[r], 0, 64), lane, untracked);
@@ -626,11 +629,11 @@ size_t relax_tiles(int h, int w) {
 // hold those rows have anything new to look at: raise, in the stamp array that the EVEN pass `pass` reads (the shifted
 // grid's), every quadrant flag of its first / last tile row, so that exactly the first / last tile row of the anchored
 // grid runs in that pass; what they change spreads by the usual flags.  The stamp arrays must be zeroed first.
-__global__ void k_flag_tile_rows(uint32_t *prev, int sx, int sy, uint32_t pass, int halo_flags) {
+__global__ void k_flag_tile_rows(uint32_t *prev, int sx, int bottom_row, uint32_t pass, int halo_flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sx * 4) return;
   if (halo_flags & 1) prev[i] = pass;
-  if (halo_flags & 2) prev[(size_t)(sy - 1) * sx * 4 + i] = pass;
+  if (halo_flags & 2) prev[(size_t)bottom_row * sx * 4 + i] = pass;
 }
 
 hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w, uint32_t pass, int halo_flags) {
@@ -638,7 +641,13 @@ hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w
   const int th = RX_NW * RX_P;
   const int sx = (w + RX_TW - 1) / RX_TW + 1, sy = (h + th - 1) / th + 1;
   const size_t cap = (size_t)sx * sy * 4;
-  k_flag_tile_rows<<<(sx * 4 + 255) / 256, 256, 0, s>>>(stamps + cap, sx, sy, pass, halo_flags);      // array 1: written by odd passes
+  // An anchored tile row t runs when row t or t + 1 of the shifted grid is flagged.  What has to run is every tile that
+  // holds a pixel NEXT to a halo row, i.e. plane rows 1 (tile row 0: shifted row 0) and h - 2 -- which need not share a
+  // tile with the halo row h - 1 itself (a block of 32 k + 1 rows: the halo row has a tile row of its own, and running
+  // only that one, whose pixels are all pinned, repairs nothing).  Shifted row (h - 2) / th + 1 starts tile row
+  // (h - 2) / th and, when it exists, the one below.
+  const int bottom_row = (h - 2) / th + 1;
+  k_flag_tile_rows<<<(sx * 4 + 255) / 256, 256, 0, s>>>(stamps + cap, sx, bottom_row, pass, halo_flags);      // array 1: written by odd passes
   return hipGetLastError();
 }
 
@@ -668,6 +677,23 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     return e ? (uint32_t)atoi(e) : 2u;
   }();
   if (pass == 0 && p0_rounds < max_iters) max_iters = p0_rounds;
+  // Late passes (the long-range regime of smooth maps: a few hundred tiles along the flood fronts per pass) end when their
+  // SLOWEST tile ends, and a tile that the front is crossing diagonally can take a dozen rounds.  Capping the rounds lets a
+  // pass end after the typical tile's work: a capped tile raises all four quadrant flags (like a capped pass-0 tile), so
+  // the tiles of the other grid that cover it carry on in the next pass -- next to the front, which has moved on meanwhile.
+  static const uint32_t late_cap = [] {
+    const char *e = tuning_env("WS_RELAX_LATE_CAP");      // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : RX_LATE_ROUND_CAP;
+  }();
+  if (pass >= RX_SCAN_FROM_PASS && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
+  static const uint32_t scan_after = [] {
+    const char *e = tuning_env("WS_RELAX_SCAN_AFTER");    // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : RX_SCAN_AFTER;
+  }();
+  static const uint32_t lite_from = [] {
+    const char *e = tuning_env("WS_RELAX_LITE_FROM");     // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : 2u;
+  }();
   // passes 0 and 1 run every tile and pass 2 about half of them (bench field): one tile per workgroup
   static const uint32_t chunk_from = [] {
     const char *e = tuning_env("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
@@ -675,21 +701,21 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }();
   const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
-  if (pass < chunk_from && pass < 2) {
+  if (pass < chunk_from && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
     if (pass < RX_SCAN_FROM_PASS)
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after);
     else
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after);
   }
   return hipGetLastError();
 }

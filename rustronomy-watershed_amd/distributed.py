@@ -50,7 +50,18 @@ def row_block(height, rank, world):
 def local_seeds(seeds, lo, hi):
     """Seeds (n, 2) in global coordinates -> (local (m, 2) int32, colours (m,) int32) for the rows
     [lo, hi) of one rank; colour = index in the caller's slice + 1 (lib.rs:1670-1672)."""
-    seeds = torch.as_tensor(seeds).to(torch.int64).reshape(-1, 2)
+    seeds = torch.as_tensor(seeds).reshape(-1, 2)
+    rows = seeds[:, 0].contiguous()
+    if rows.numel() > 1 and bool((rows[1:] >= rows[:-1]).all()):
+        # rows in non-decreasing order (every row-major sorted list, find_local_minima's in particular): the rank's seeds
+        # are ONE contiguous range of the list, found by two binary searches -- no 100-M-element masks or index lists
+        bounds = torch.searchsorted(rows, torch.tensor([lo, hi], dtype=rows.dtype, device=rows.device))
+        i0, i1 = int(bounds[0]), int(bounds[1])
+        loc = seeds[i0:i1].to(torch.int32).clone()
+        loc[:, 0] -= lo
+        colours = torch.arange(i0 + 1, i1 + 1, dtype=torch.int32, device=seeds.device)
+        return loc.contiguous(), colours
+    seeds = seeds.to(torch.int64)
     idx = torch.nonzero((seeds[:, 0] >= lo) & (seeds[:, 0] < hi)).flatten()
     loc = seeds[idx].clone()
     loc[:, 0] -= lo
@@ -95,6 +106,7 @@ class HipBlockEngine:
                                        self.seeds.data_ptr() if n else None, n, self.first_colour, self.keys.data_ptr())
         if rc == _ffi.WS_ERR_UNSUPPORTED:
             self.fast = False
+            self.why_not_fast = _ffi.lib().ws_last_error(self.eng.ctx.handle).decode()
             return False
         self._check(rc)
         return True
