@@ -45,7 +45,7 @@ struct ws_ctx {
   ws_stats stats{};
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
-  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab;
+  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
@@ -311,6 +311,8 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   if ((rc = ensure(c, c->keys, (n ? n : 1) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->stamps, std::max(ntiles, relax_tiles(ph, pw)) * 4 * 2 * sizeof(uint32_t)))) return rc;
   if (tables && (rc = ensure(c, c->seed_tab, (nwords ? nwords : 1) * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->tile_list, relax_list_words(ph, pw) * sizeof(uint32_t)))) return rc;
+  uint32_t *tile_list = (uint32_t *)c->tile_list.p;
   uint32_t *keys = (uint32_t *)c->keys.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
   uint32_t *stamps = (uint32_t *)c->stamps.p;
@@ -354,7 +356,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     hipError_t e = seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
                                relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
-      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded);
+      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list);
     const uint32_t last = GRAPH_PASSES - 1;
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
@@ -424,7 +426,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto launch_pass = [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded);
+                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list);
   };
   if (graph_mode != 0) {
     // the graph ran seed tables, passes 0 .. GRAPH_PASSES - 1, the gated resolve and the read-backs
@@ -739,7 +741,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->seeds64,
-                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab})
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -969,6 +971,8 @@ int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure(c, c->stamps, relax_tiles((int)h, (int)w) * 4 * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->tile_list, relax_list_words((int)h, (int)w) * sizeof(uint32_t)))) return rc;
+  uint32_t *tile_list = (uint32_t *)c->tile_list.p;
   uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_ANY, 0, FLAG_SLOT * sizeof(uint32_t), c->stream));
@@ -976,7 +980,7 @@ int ws_block_relax(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   pf.stats = nullptr;
   uint32_t passes = 0;
   rc = pass_loop(c, flags, relax_tiles((int)h, (int)w), &passes, [&](uint32_t pass) {
-    return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, pf, c->debug_max_iters);
+    return relax_pass(c->stream, d_img, stride, d_keys, (int)h, (int)w, max_water_level, pass, stamps, pf, c->debug_max_iters, nullptr, false, 0, false, false, tile_list);
   });
   if (rc) return rc;
   c->stats.relax_passes += passes;
@@ -1047,6 +1051,8 @@ int ws_block_begin(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   if ((rc = ensure(c, c->stamps, std::max((size_t)tiles_of(pw) * tiles_of(ph), relax_tiles(ph, pw)) * 4 * 2 * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->seed_tab, nwords * 2 * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->tile_list, relax_list_words(ph, pw) * sizeof(uint32_t)))) return rc;
+  uint32_t *tile_list = (uint32_t *)c->tile_list.p;
   uint32_t *flags = (uint32_t *)c->flags.p, *stamps = (uint32_t *)c->stamps.p;
   uint32_t *seed_mask = (uint32_t *)c->seed_tab.p, *word_base = seed_mask + nwords;
   c->have_keys = false;
@@ -1059,7 +1065,7 @@ int ws_block_begin(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t s
   const PassFlags pf = make_pf(c);
   rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
-    return relax_pass(c->stream, d_img, stride, d_keys, ph, pw, max_water_level, pass, stamps, pf, c->debug_max_iters, seed_mask, true, 0, true);
+    return relax_pass(c->stream, d_img, stride, d_keys, ph, pw, max_water_level, pass, stamps, pf, c->debug_max_iters, seed_mask, true, 0, true, false, tile_list);
   }, true, 5);
   if (rc) return rc;
   c->stats.launches_relax = c->stats.relax_passes;
@@ -1087,13 +1093,14 @@ int ws_block_relax_halo(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, siz
   stats_begin(c);
   HIP_TRY(c, hipMemsetAsync(stamps, 0, ntiles * 4 * 2 * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(flags + FLAG_EDGE, 0, COUNTER_RING * FLAG_SLOT * sizeof(uint32_t), c->stream));
+  uint32_t *tile_list = (uint32_t *)c->tile_list.p;      // sized by ws_block_begin
   constexpr uint32_t FIRST = 4;      // an even pass of the late kind: few tiles run (chunked launches, long-range scans)
   HIP_TRY(c, block_flag_border_tiles(c->stream, stamps, ph, pw, FIRST, halo));
   const PassFlags pf = make_pf(c);
   uint32_t last = 0;
   int rc = pass_loop(c, flags, ntiles, &last, [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
-    return relax_pass(c->stream, d_img, stride, d_keys, ph, pw, max_water_level, pass, stamps, pf, c->debug_max_iters, nullptr, false, 0, true);
+    return relax_pass(c->stream, d_img, stride, d_keys, ph, pw, max_water_level, pass, stamps, pf, c->debug_max_iters, nullptr, false, 0, true, false, tile_list);
   }, true, 2, nullptr, nullptr, FIRST);
   if (rc) return rc;
   c->stats.relax_passes = last - FIRST;

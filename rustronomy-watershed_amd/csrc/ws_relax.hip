@@ -33,6 +33,7 @@
 // that exist only when profiling is on.
 #include "ws_common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace wsk {
@@ -254,7 +255,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
-                                                      int pad, uint32_t scan_after) {
+                                                      int pad, uint32_t scan_after, uint32_t *tile_list, int use_list) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -277,13 +278,21 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // the first wave of workgroup 0 clears the next pass's convergence slot
   if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
     pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
+  // ... and the length of the next pass's tile list (k_relax_list appends to it after this launch has ended)
+  if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) tile_list[(pass + 1) & 1u] = 0u;
   // (XCD-aware: consecutive workgroups go to different XCDs; see xcd_span_index)
   // A chunk is `chunk` tiles one grid size apart, not neighbours: on a smooth map the tiles that still
   // run line up along a front, and four neighbours in one workgroup ran one after the other.
   const int first = (int)xcd_span_index(blockIdx.x, gridDim.x);
   const int stride = (int)gridDim.x;
   unsigned long long todo = 1;
-  if (CHUNKED) {
+  // list mode (late passes of a long-range flood): the tiles to run were compacted by k_relax_list; workgroup b takes
+  // entries b, b + gridDim.x, ... -- no workgroup is launched for a tile that has nothing to do, none owns two busy ones
+  uint32_t entry = blockIdx.x, n_entries = 0;
+  if (CHUNKED && use_list) {
+    n_entries = tile_list[pass & 1u];
+    if (entry >= n_entries) return;
+  } else if (CHUNKED) {
     todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
     if (todo == 0) return;
   } else {
@@ -309,7 +318,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   int tid = threadIdx.x;
   if (CHUNKED) asm volatile("" : "+v"(tid));
   const int lane = tid & 63, band = tid >> 6;
-  const int tile = CHUNKED ? first + (int)__builtin_ctzll(todo) * stride : first;
+  const int tile = CHUNKED ? (use_list ? (int)tile_list[2 + entry] : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = tile_x * RX_TW - (shifted ? RX_TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
@@ -612,12 +621,40 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   WS_STAMP(3);
   // next tile of the chunk: every wave is past its last read of the shared arrays (barrier above)
   if (!CHUNKED) break;
-  todo &= todo - 1;
-  if (todo == 0) break;
+  if (use_list) {
+    entry += gridDim.x;
+    if (entry >= n_entries) break;
+  } else {
+    todo &= todo - 1;
+    if (todo == 0) break;
+  }
   }
 }
 
 constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
+
+// The tiles that have to run in `pass`, compacted: tile_list[pass & 1] = how many, tile_list[2 ...] = which (any order).
+// Same test as relax_todo; one atomicAdd per wave that found any.  Worth its own launch only when few tiles run: on a
+// smooth map a pass moves the flood fronts by one tile, a few hundred tiles out of thousands, and the chunked launch
+// (a workgroup per four tiles, most of them idle, some with two busy ones to run back to back) took twice as long as
+// the tiles themselves.
+constexpr uint32_t RX_LIST_FROM_PASS = 6;      // the bench field has converged by then (its passes 4 and 5 find nothing to do)
+constexpr unsigned RX_LIST_GRID = 1024;
+
+__global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, int tilesY, int otherX, int otherY, int shifted,
+                                                    uint32_t pass, const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list) {
+  const int lane = threadIdx.x & 63;
+  const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);      // this wave's 64 consecutive tiles
+  const unsigned long long todo = relax_todo<RX_NW>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
+  if (todo == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&tile_list[pass & 1u], (uint32_t)__popcll(todo));
+  base = __shfl(base, 0, 64);
+  if ((todo >> lane) & 1ull) tile_list[2 + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
+}
+
+// words of scratch relax_pass wants for its tile lists
+size_t relax_list_words(int h, int w) { return 2 + relax_tiles(h, w); }
 
 // capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column
 size_t relax_tiles(int h, int w) {
@@ -653,7 +690,8 @@ hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
-                      const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded) {
+                      const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded,
+                      uint32_t *tile_list) {
   const int th = RX_NW * RX_P;
   const int pad = padded ? 1 : 0;
   // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
@@ -703,19 +741,32 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
-    if (pass < RX_SCAN_FROM_PASS)
+    static const uint32_t list_from = [] {
+      const char *e = tuning_env("WS_RELAX_LIST_FROM");      // tuning knob, tools/ only
+      return e ? (uint32_t)atoi(e) : RX_LIST_FROM_PASS;
+    }();
+    if (pass < RX_SCAN_FROM_PASS) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after);
-    else
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0);
+    } else if (tile_list && pass >= list_from && pass >= RX_SCAN_FROM_PASS + 1) {
+      // (the pass before the first list pass has cleared this pass's counter: every kernel variant does, given a list)
+      k_relax_list<<<(unsigned)((tx * ty + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      k_relax<RX_NW, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(tx * ty)), 64 * RX_NW, 0, s>>>(
+          img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
+          check_carry, pad, scan_after, tile_list, 1);
+    } else {
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0);
+    }
   }
   return hipGetLastError();
 }
