@@ -80,6 +80,19 @@ struct ws_ctx {
     }
   };
   GraphKey graph_key, seen_key;      // of graph_exec / of the previous transform
+  // the per-level loop of transform_to_list / the merging final labels, captured in groups of levels (merge_host)
+  struct ListKey {
+    bool merging = false, want_list = false;
+    uint32_t levels = 0;
+    size_t n_colours = 0, n = 0, cap = 0;
+    uint64_t generation = 0;
+    bool operator==(const ListKey &o) const {
+      return generation == o.generation && generation != 0 && merging == o.merging && want_list == o.want_list && levels == o.levels &&
+             n_colours == o.n_colours && n == o.n && cap == o.cap;
+    }
+  };
+  ListKey list_graph_key, list_seen_key;
+  hipGraphExec_t list_graphs[16]{};
   hipGraphExec_t graph_exec = nullptr;
   bool graph_unusable = false;       // capture failed once on this stream: not tried again
   uint64_t buffer_generation = 1;    // bumped whenever a device buffer of the context is reallocated
@@ -745,6 +758,7 @@ void ws_ctx_destroy(ws_ctx *c) {
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (hipGraphExec_t g : c->list_graphs) if (g) (void)hipGraphExecDestroy(g);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < COUNTER_RING; ++i) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
   for (int i = 0; i < COUNTER_RING; ++i) if (c->kern_ev[i]) (void)hipEventDestroy(c->kern_ev[i]);
@@ -1162,40 +1176,28 @@ constexpr int MF_HIST_PX = 0;
 constexpr int MF_HIST_ED = NLEVELS;
 constexpr int MF_CUR_PX = 2 * NLEVELS;
 constexpr int MF_CUR_ED = 3 * NLEVELS;
-constexpr int MF_LAKE_CURSOR = 4 * NLEVELS;
 constexpr int MF_HOOKED = 5 * NLEVELS + 16;               // NLEVELS u32 counters (one per level: no memset between levels)
 constexpr int MF_LAKE_COUNT = 6 * NLEVELS + 16;           // NLEVELS u64 per-level record counters
-constexpr int MF_WORDS = 8 * NLEVELS + 24;
+constexpr int MF_OFF_PX = 8 * NLEVELS + 24;               // NLEVELS + 1 bucket bounds of the arriving pixels (k_level_offsets)
+constexpr int MF_OFF_ED = MF_OFF_PX + NLEVELS + 1;        // ... and of the crossing edges
+constexpr int MF_WORDS = MF_OFF_ED + NLEVELS + 1;
 constexpr uint32_t LIST_GROUP = 16;                       // levels per host copy of lake records (16 groups: kern_ev has 64)
 
-struct LevelBuckets {
-  std::vector<uint64_t> off_px, off_ed;    // NLEVELS + 1 prefix sums
-};
-
-// Segmenting result (stamps + colours) -> per-level buckets of arriving pixels and crossing edges.
-int build_buckets(ws_ctx *c, const uint32_t *keys, const uint32_t *seg_labels, int ph, int pw, LevelBuckets *lb) {
+// Segmenting result (stamps + colours) -> per-level buckets of arriving pixels and crossing edges, all on the device:
+// histograms, their prefix sums (the bucket bounds, which only kernels ever read), scatter.  Nothing is read back, so
+// the buffers are sized by what a plane can hold: one arrival per pixel, two crossing edges (right, down) per pixel.
+int build_buckets(ws_ctx *c, const uint32_t *keys, const uint32_t *seg_labels, int ph, int pw) {
   int rc;
+  const size_t n = (size_t)ph * pw;
   if ((rc = ensure(c, c->mflags, MF_WORDS * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(c, c->px_items, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->edge_items, (n ? 2 * n : 1) * sizeof(uint2)))) return rc;
   u64c *mf = (u64c *)c->mflags.p;
   HIP_TRY(c, hipMemsetAsync(mf, 0, MF_WORDS * sizeof(uint64_t), c->stream));
   HIP_TRY(c, level_hist(c->stream, keys, seg_labels, ph, pw, mf + MF_HIST_PX, mf + MF_HIST_ED));
-  std::vector<uint64_t> hist(2 * NLEVELS);
-  HIP_TRY(c, hipMemcpyAsync(hist.data(), mf, 2 * NLEVELS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  lb->off_px.assign(NLEVELS + 1, 0);
-  lb->off_ed.assign(NLEVELS + 1, 0);
-  for (int l = 0; l < NLEVELS; ++l) {
-    lb->off_px[l + 1] = lb->off_px[l] + hist[MF_HIST_PX + l];
-    lb->off_ed[l + 1] = lb->off_ed[l] + hist[MF_HIST_ED + l];
-  }
-  const size_t npx = lb->off_px[NLEVELS], ned = lb->off_ed[NLEVELS];
-  if ((rc = ensure(c, c->px_items, (npx ? npx : 1) * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(c, c->edge_items, (ned ? ned : 1) * sizeof(uint2)))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(mf + MF_CUR_PX, lb->off_px.data(), NLEVELS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(mf + MF_CUR_ED, lb->off_ed.data(), NLEVELS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, level_offsets(c->stream, mf + MF_HIST_PX, mf + MF_HIST_ED, mf + MF_OFF_PX, mf + MF_OFF_ED, mf + MF_CUR_PX, mf + MF_CUR_ED));
   HIP_TRY(c, level_scatter(c->stream, keys, seg_labels, ph, pw, mf + MF_CUR_PX, mf + MF_CUR_ED,
                            (uint32_t *)c->px_items.p, (uint2 *)c->edge_items.p));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));      // off_* vectors were the copy sources
   return WS_OK;
 }
 
@@ -1204,30 +1206,28 @@ int ensure_uf(ws_ctx *c, size_t n_colours) {
   if ((rc = ensure(c, c->uf_parent, n_colours * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->uf_size, n_colours * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->uf_hooked, n_colours * sizeof(uint32_t)))) return rc;
-  HIP_TRY(c, uf_init(c->stream, (uint32_t *)c->uf_parent.p, (uint32_t *)c->uf_size.p, n_colours));
   return WS_OK;
 }
 
-// Per-level driver shared by the merging hook and both transform_to_list flavours.
+// workgroups of the per-level kernels: their buckets' sizes are only known on the device, so the grid follows the plane
+// (an even spread would be pixels / 255 per level) and the kernels stride
+unsigned level_grid(size_t n_px) { return (unsigned)std::min<size_t>(std::max<size_t>(n_px / (256 * 64), 8), 2048); }
+
+// Levels [l0, l1) of the per-level driver shared by the merging hook and both transform_to_list flavours; launches only.
 //   merging: union this level's crossing edges (lib.rs:1449-1466 in closed form)
 //   want_sizes: keep per-lake areas (lib.rs:628-635)
-//   per_level(l): called after level l is complete (device state current on c->stream)
+//   per_level(l): called after level l is queued (device state current on c->stream)
 template <class F>
-int level_loop(ws_ctx *c, const LevelBuckets &lb, uint32_t max_level, bool merging, bool want_sizes, F per_level) {
+int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_sizes, unsigned grid, F per_level) {
   uint32_t *parent = (uint32_t *)c->uf_parent.p, *size = (uint32_t *)c->uf_size.p, *hooked = (uint32_t *)c->uf_hooked.p;
   u64c *mf = (u64c *)c->mflags.p;
   uint32_t *hooked_count = (uint32_t *)(mf + MF_HOOKED);
   const uint32_t *px_items = (const uint32_t *)c->px_items.p;
   const uint2 *edge_items = (const uint2 *)c->edge_items.p;
-  for (uint32_t l = 0; l <= max_level; ++l) {
-    const size_t e0 = lb.off_ed[l], e1 = lb.off_ed[l + 1], p0 = lb.off_px[l], p1 = lb.off_px[l + 1];
-    const bool unions = merging && e1 > e0;
-    if (unions) {
-      HIP_TRY(c, union_edges(c->stream, edge_items + e0, e1 - e0, parent, want_sizes ? hooked : nullptr, hooked_count + l));
-      c->stats.merge_levels++;
-    }
+  for (uint32_t l = l0; l < l1; ++l) {
+    if (merging) HIP_TRY(c, union_edges_ranged(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, want_sizes ? hooked : nullptr, hooked_count + l));
     // areas of the nodes hooked in this level move to their roots, arriving pixels are counted: one launch
-    if (want_sizes) HIP_TRY(c, fold_and_add(c->stream, unions ? hooked : nullptr, hooked_count + l, px_items + p0, p1 - p0, parent, size));
+    if (want_sizes) HIP_TRY(c, fold_and_add_ranged(c->stream, merging ? hooked : nullptr, hooked_count + l, px_items, mf + MF_OFF_PX + l, grid, parent, size));
     int rc = per_level(l);
     if (rc) return rc;
   }
@@ -1256,35 +1256,21 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   // the flood itself is the segmenting one (same coloured set, same arrival stamps: lib.rs:1394-1438 == 1704-1748)
   if ((rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, seg, opt->edge_correction != 0))) return rc;
   const uint32_t *keys = (const uint32_t *)c->keys.p;
-  uint32_t *parent;
-  LevelBuckets lb;
-  if (n) {
-    if ((rc = build_buckets(c, keys, seg, (int)ph, (int)pw, &lb))) return rc;
-  } else {
-    lb.off_px.assign(NLEVELS + 1, 0);
-    lb.off_ed.assign(NLEVELS + 1, 0);
-  }
+  // every buffer first, so that nothing moves once launches (or captured graphs) hold its address
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
-  parent = (uint32_t *)c->uf_parent.p;
+  if (want_list && (rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
+  if ((rc = build_buckets(c, keys, seg, (int)ph, (int)pw))) return rc;
+  uint32_t *parent = (uint32_t *)c->uf_parent.p;
   u64c *mf = (u64c *)c->mflags.p;
-  if (want_list) {
-    if ((rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
-    if ((rc = ensure(c, c->mflags, MF_WORDS * sizeof(uint64_t)))) return rc;
-    mf = (u64c *)c->mflags.p;
-    HIP_TRY(c, hipMemsetAsync(mf + MF_LAKE_CURSOR, 0, (MF_WORDS - MF_LAKE_CURSOR) * sizeof(uint64_t), c->stream));
-  }
+  HIP_TRY(c, uf_init(c->stream, parent, (uint32_t *)c->uf_size.p, n_seeds + 1));
   const uint8_t *himg = cb ? hook_image(c, img, h, w, stride, opt->edge_correction) : nullptr;
   if (cb) c->host64.resize(n ? n : 1);
+  const uint32_t levels = (uint32_t)opt->max_water_level + 1;
+  const unsigned grid = level_grid(n);
 
-  rc = level_loop(c, lb, opt->max_water_level, merging, want_list, [&](uint32_t l) -> int {
-    if (want_list) {
-      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
-      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap,
-                            mf + MF_LAKE_COUNT, l));
-      // every LIST_GROUP levels (and after the last): a marker, so that the records of finished levels can travel to
-      // the host while later levels are still being computed
-      if ((l + 1) % LIST_GROUP == 0 || l == opt->max_water_level) HIP_TRY(c, hipEventRecord(c->kern_ev[l / LIST_GROUP], c->stream));
-    }
+  auto per_level = [&](uint32_t l) -> int {
+    if (want_list)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_COUNT, l));
     if (cb) {
       if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
       else HIP_TRY(c, snapshot_level(c->stream, keys, seg, d_out64, n, l));
@@ -1293,19 +1279,62 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
       cb(user, (uint8_t)l, opt->max_water_level, himg, c->host64.data(), ph, pw);        // lib.rs:1510-1518
     }
     return WS_OK;
-  });
-  if (rc) return rc;
+  };
 
+  // The level loop is ~3 launches of a few microseconds per level and has no host decision in it: a call that repeats
+  // the previous one's shape and buffers replays it as hipGraphs, one per group of LIST_GROUP levels (the groups' record
+  // copies still overlap the later groups).  The second such call captures, later ones replay.
+  ws_ctx::ListKey key;
+  key.merging = merging; key.want_list = want_list; key.levels = levels; key.n_colours = n_seeds + 1; key.n = n; key.cap = cap;
+  key.generation = c->buffer_generation;
+  const bool graph_able = !cb && c->stream != nullptr && !c->graph_unusable && !c->profiling && n != 0;
+  bool use_graphs = graph_able && key == c->list_seen_key;
+  c->list_seen_key = graph_able ? key : ws_ctx::ListKey();
+  if (!(use_graphs && key == c->list_graph_key)) {      // another shape: yesterday's graphs are of no use
+    for (hipGraphExec_t &g : c->list_graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    c->list_graph_key = use_graphs ? key : ws_ctx::ListKey();
+  }
+  for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
+    const uint32_t g1 = std::min(g0 + LIST_GROUP, levels), gi = g0 / LIST_GROUP;
+    bool done = false;
+    if (use_graphs) {
+      if (!c->list_graphs[gi]) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int lrc = level_range(c, g0, g1, merging, want_list, grid, per_level);
+          const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+          if (lrc == WS_OK && e2 == hipSuccess && hipGraphInstantiate(&c->list_graphs[gi], graph, nullptr, nullptr, 0) != hipSuccess) c->list_graphs[gi] = nullptr;
+          if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!c->list_graphs[gi]) {      // nothing ran: plain launches from here on, for good
+          (void)hipGetLastError();
+          c->graph_unusable = true;
+          use_graphs = false;
+        }
+      }
+      if (c->list_graphs[gi]) {
+        HIP_TRY(c, hipGraphLaunch(c->list_graphs[gi], c->stream));
+        c->stats.graph_launches++;
+        done = true;
+      }
+    }
+    if (!done && (rc = level_range(c, g0, g1, merging, want_list, grid, per_level))) return rc;
+    // a marker per group, so that the records of finished levels can travel to the host while later levels are computed
+    if (want_list) HIP_TRY(c, hipEventRecord(c->kern_ev[gi], c->stream));
+  }
+
+  std::vector<uint64_t> bounds(2 * (NLEVELS + 1));
   if (want_list) {
     // All levels are queued.  Group by group: wait for the group's marker, read its offsets, copy its records
     // (155 MB at 1024^2: as long over PCIe as the levels take to compute, so the two are overlapped).
-    const uint32_t levels = (uint32_t)opt->max_water_level + 1;
     offsets[0] = 0;
     size_t copied = 0;
     for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
       const uint32_t g1 = std::min(g0 + LIST_GROUP, levels);
       HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g0 / LIST_GROUP], 0));
       HIP_TRY(c, hipMemcpyAsync(offsets + g0 + 1, mf + MF_LAKE_COUNT + g0, (g1 - g0) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+      if (g0 == 0)      // the bucket bounds were final before the first level: they ride along with the first group
+        HIP_TRY(c, hipMemcpyAsync(bounds.data(), mf + MF_OFF_PX, 2 * (NLEVELS + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
       HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
       for (uint32_t l = g0; l < g1; ++l) offsets[l + 1] += offsets[l];      // counts -> offsets
       const size_t end = std::min<size_t>(offsets[g1], cap);
@@ -1316,7 +1345,9 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     }
     HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     *n_lakes = offsets[levels];
-    for (uint32_t l = 0; l < levels; ++l) uncoloured[l] = n - lb.off_px[l + 1];                // index 0 of lib.rs:630's vector
+    for (uint32_t l = 0; l < levels; ++l) uncoloured[l] = n - bounds[l + 1];                   // index 0 of lib.rs:630's vector
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(bounds.data(), mf + MF_OFF_PX, 2 * (NLEVELS + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   }
   if (out_labels && n) {
     if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, opt->max_water_level));
@@ -1325,6 +1356,8 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   }
   rc = stats_end(c);
   if (rc) return rc;
+  if (merging)
+    for (uint32_t l = 0; l < levels; ++l) c->stats.merge_levels += bounds[NLEVELS + 1 + l + 1] > bounds[NLEVELS + 1 + l] ? 1u : 0u;
   if (want_list && *n_lakes > cap) return fail(c, WS_ERR_CAPACITY, "lake buffer too small");
   return WS_OK;
 }
@@ -1436,6 +1469,7 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   c->tile_min_out = nullptr;
   if (rc) return rc;
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
+  HIP_TRY(c, uf_init(c->stream, (uint32_t *)c->uf_parent.p, (uint32_t *)c->uf_size.p, n_seeds + 1));
   {
     Span sp(c, KC_OTHER);
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed

@@ -138,6 +138,33 @@ hipError_t level_hist(hipStream_t s, const uint32_t *keys, const uint32_t *label
   return hipGetLastError();
 }
 
+// Exclusive prefix sums of the two histograms, on the device: off[l] = first item of level l, off[256] = total; the
+// scatter cursors start at the same values.  (The host used to do this between two synchronisations.)
+__global__ __launch_bounds__(NLEVELS) void k_level_offsets(const u64c *__restrict__ hist_px, const u64c *__restrict__ hist_ed,
+                                                           u64c *off_px, u64c *off_ed, u64c *cur_px, u64c *cur_ed) {
+  __shared__ u64c s_a[NLEVELS], s_b[NLEVELS];
+  const int t = threadIdx.x;
+  const u64c a0 = hist_px[t], b0 = hist_ed[t];
+  s_a[t] = a0;
+  s_b[t] = b0;
+  __syncthreads();
+  for (int o = 1; o < NLEVELS; o <<= 1) {            // Hillis-Steele inclusive scan
+    const u64c a = t >= o ? s_a[t - o] : 0ull, b = t >= o ? s_b[t - o] : 0ull;
+    __syncthreads();
+    s_a[t] += a;
+    s_b[t] += b;
+    __syncthreads();
+  }
+  off_px[t] = cur_px[t] = s_a[t] - a0;
+  off_ed[t] = cur_ed[t] = s_b[t] - b0;
+  if (t == NLEVELS - 1) { off_px[NLEVELS] = s_a[t]; off_ed[NLEVELS] = s_b[t]; }
+}
+
+hipError_t level_offsets(hipStream_t s, const u64c *hist_px, const u64c *hist_ed, u64c *off_px, u64c *off_ed, u64c *cur_px, u64c *cur_ed) {
+  k_level_offsets<<<1, NLEVELS, 0, s>>>(hist_px, hist_ed, off_px, off_ed, cur_px, cur_ed);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_level_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
                                                        int H, int W, int segs, u64c *cursor_px, u64c *cursor_edge,
                                                        uint32_t *px_items, uint2 *edge_items) {
@@ -193,8 +220,10 @@ hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *la
 
 // ---- per-level union / sizes / emit -----------------------------------------------------
 
+// range (nullable): {first, end} item indices in device memory -- the level's bucket, whose bounds the host never reads
 __global__ void k_union_edges(const uint2 *__restrict__ edges, size_t n, uint32_t *parent, uint32_t *hooked,
-                              uint32_t *hooked_count) {
+                              uint32_t *hooked_count, const u64c *__restrict__ range) {
+  if (range) { edges += range[0]; n = (size_t)(range[1] - range[0]); }
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += step) {
@@ -208,7 +237,13 @@ hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *pa
                        uint32_t *hooked_count) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  k_union_edges<<<blocks, 256, 0, s>>>(edges, n, parent, hooked, hooked_count);
+  k_union_edges<<<blocks, 256, 0, s>>>(edges, n, parent, hooked, hooked_count, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t union_edges_ranged(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned grid, uint32_t *parent, uint32_t *hooked,
+                              uint32_t *hooked_count) {
+  k_union_edges<<<grid, 256, 0, s>>>(edge_items, 0, parent, hooked, hooked_count, range);
   return hipGetLastError();
 }
 
@@ -220,7 +255,9 @@ hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *pa
 // launch gaps are most of its time).  They do not interfere: folding reads the areas of nodes hooked in this level --
 // no longer roots, so no arrival is added to them -- and both add to roots.
 __global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
-                               const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size) {
+                               const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size,
+                               const u64c *__restrict__ range) {
+  if (range) { px_items += range[0]; n = (size_t)(range[1] - range[0]); }
   const int lane = threadIdx.x & 63;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   if (hooked) {
@@ -250,7 +287,13 @@ hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *h
                         uint32_t *parent, uint32_t *size) {
   if (!hooked && n == 0) return hipSuccess;
   const size_t want = std::max<size_t>((n + 255) / 256, hooked ? 512 : 1);
-  k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size);
+  k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t fold_and_add_ranged(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items,
+                               const u64c *range, unsigned grid, uint32_t *parent, uint32_t *size) {
+  k_fold_and_add<<<grid, 256, 0, s>>>(hooked, hooked_count, px_items, 0, parent, size, range);
   return hipGetLastError();
 }
 

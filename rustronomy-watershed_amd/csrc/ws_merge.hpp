@@ -31,6 +31,15 @@ hipError_t level_hist(hipStream_t s, const uint32_t *keys, const uint32_t *label
 hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *labels, int h, int w,
                          u64c *cursor_px, u64c *cursor_edge, uint32_t *px_items, uint2 *edge_items);
 
+// exclusive prefix sums of the histograms (NLEVELS + 1 entries each) and the scatter cursors, all on the device
+hipError_t level_offsets(hipStream_t s, const u64c *hist_px, const u64c *hist_ed, u64c *off_px, u64c *off_ed, u64c *cur_px, u64c *cur_ed);
+// the per-level kernels on a bucket whose bounds {first, end} sit in device memory (range = off + level): fixed grid,
+// grid-stride loops -- nothing the host has to read before it launches, so the whole level loop can be captured
+hipError_t union_edges_ranged(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned grid, uint32_t *parent, uint32_t *hooked,
+                              uint32_t *hooked_count);
+hipError_t fold_and_add_ranged(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items,
+                               const u64c *range, unsigned grid, uint32_t *parent, uint32_t *size);
+
 // lock-free union-by-min of n edges; every node that loses its root status is appended to hooked
 hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *parent, uint32_t *hooked,
                        uint32_t *hooked_count);
