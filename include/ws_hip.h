@@ -34,9 +34,13 @@
  *   - SegmentingWatershed::transform as written panics (lib.rs:1821 indexes the
  *     level-0 hook result); ws_segment returns the intended result, the labels after
  *     the last level (what transform_history(..).last() yields, lib.rs:1824-1835);
- *   - merged-lake representative ids are arbitrary in the reference (sort/dedup order,
- *     lib.rs:440-443, 508-541); this engine returns the canonical one: the smallest
- *     seed colour whose seed pixel lies in the lake.
+ *   - merged-lake ids DIFFER IN VALUE from the reference's: there a merged lake takes region[0] of
+ *     make_colour_map's closure (lib.rs:508-541), which is a function of the order of the pair list
+ *     (parallel unstable sort + dedup, lib.rs:440-443) -- deterministic for a given list, but not a
+ *     property of the lake.  This engine returns the canonical id: the smallest seed colour whose
+ *     seed pixel lies in the lake.  The PARTITION into lakes is the reference's (tested against the
+ *     oracle's faithful closure under random tie-breaks); the id values are a documented deviation,
+ *     "parity unpinned" by the reference (it has no test or fixture for them).
  */
 #ifndef WS_HIP_H
 #define WS_HIP_H

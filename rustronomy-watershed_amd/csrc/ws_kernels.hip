@@ -969,7 +969,8 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const uint32_t t = out[r][c] - 1u; lo = min(lo, t); hi = max(hi, t); }
     } else {
-      // image-border pixels never flood (lib.rs:1693-1697 pads with NEVER_FILL): only interior pixels decide "one lake";
+      // image-border pixels never flood (the flood step only visits 3x3 window centres, lib.rs:220-222; edge correction pads
+      // with zeros, lib.rs:1340-1352, whose ring is then the border): only interior pixels decide "one lake";
       // a corner pixel touches no interior pixel, its colour never merges and must not stand for the tile
 #pragma unroll
       for (int r = 0; r < 4; ++r)
