@@ -659,7 +659,14 @@ int ws_or_pre_processor(const void *data, int dtype, size_t n, uint8_t max_value
     const double v = pre_get(data, dtype, i);
     if (isnormal(v)) {                                     /* lib.rs:1161 */
       const double normal = (v - mn) / (mx - mn);          /* lib.rs:1163 */
-      out[i] = (uint8_t)(normal * (double)max_value);      /* lib.rs:1164: to_u8 truncates */
+      /* lib.rs:1164: `(normal * MAX).to_u8().unwrap()` truncates toward zero and PANICS outside 0..=255.  With the
+       * zero-seeded folds mn <= 0 <= mx, and for finite v: mn <= v <= mx, so 0 <= normal <= 1 and the product lies
+       * in [0, MAX] (MAX <= 254): the cast below is the reference's value wherever the reference returns one.  The only
+       * inputs outside that are mx == mn (all values 0 / non-finite: no `normal` branch is taken) -- asserted, so that
+       * an out-of-range product is an error here too instead of an undefined C conversion. */
+      const double scaled = normal * (double)max_value;
+      if (!(scaled >= 0.0 && scaled < 256.0)) return -2;    /* the reference would panic (unwrap on None) */
+      out[i] = (uint8_t)scaled;
     } else if (isinf(v) && !signbit(v)) {
       out[i] = WS_OR_ALWAYS_FILL;                          /* lib.rs:1165-1167: +inf */
     } else {
