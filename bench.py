@@ -5,6 +5,7 @@
 
 headline (default)  one 8192x8192 u8 random field per GPU, device-resident: BASELINE's metric.  N GPUs = N independent
                     fields, no collective on the data path ("weak").
+c3                  BASELINE config 3: the MERGING transform (final canonical labels) of one 8192x8192 field per GPU.
 c4                  BASELINE config 4: a batch of 64 independent 4096x4096 slices, slice i on rank i % N, each rank's
                     slices as ONE stacked transform (ws_segment_batch_device).  Total work fixed ("strong").
 c5                  BASELINE config 5: one 32768x32768 field in row blocks over the ranks, halo rows exchanged through
@@ -41,7 +42,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20)      # transforms are 0.6 ms: twenty bring the clocks up and let the graph capture (2nd call) settle
-    ap.add_argument("--config", choices=["headline", "c4", "c5"], default="headline")
+    ap.add_argument("--config", choices=["headline", "c3", "c4", "c5"], default="headline")
     ap.add_argument("--size", type=int, default=0, help="override the field side (headline: 8192, c4 slices: 4096, c5: 32768)")
     ap.add_argument("--slices", type=int, default=C4_SLICES, help="c4: slices in the batch")
     ap.add_argument("--engine", choices=["fused", "sweep"], default="fused")
@@ -207,7 +208,7 @@ def run(args):
 
     # ---- the configuration's input, resident in HBM, and its step ------------------------------------------------------
     cfg = args.config
-    if cfg == "headline":
+    if cfg in ("headline", "c3"):
         H = W = args.size or 8192
         img = eng.random_field(H, W, 1 + rank)          # one independent field per rank
         seeds = eng.find_local_minima(img)
@@ -215,10 +216,13 @@ def run(args):
         n_seeds = int(seeds.shape[0])
         px_per_step_all_ranks = world * H * W
         scaling = "weak"
-
-        def step():
-            eng.segment(img, seeds, out=labels)
-        workload = (f"{H}x{W} u8 uniform[0,254) random field per GPU, segmenting transform, max_water_level 254, "
+        if cfg == "c3":
+            def step():
+                eng.merge(img, seeds, out=labels)       # segmenting flood + one union pass over the image + relabel
+        else:
+            def step():
+                eng.segment(img, seeds, out=labels)
+        workload = (f"{H}x{W} u8 uniform[0,254) random field per GPU, {'MERGING transform (final canonical labels)' if cfg == 'c3' else 'segmenting transform'}, max_water_level 254, "
                     f"seeds = find_local_minima ({n_seeds} on rank 0), engine {args.engine}")
         parallelism = f"independent fields x{world}"
         units = {"fields_per_gpu": 1}
@@ -304,13 +308,15 @@ def run(args):
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         value = px_per_step_all_ranks * args.steps / dt_max / 1e6
-        npx_rank = px_per_step_all_ranks // world if cfg != "headline" else H * W      # pixels this rank's step covers
+        npx_rank = px_per_step_all_ranks // world if cfg not in ("headline", "c3") else H * W      # pixels this rank's step covers
         if cfg == "c4":
             npx_rank = len(mine) * H * W
         n_seeds_rank = n_seeds if cfg != "c5" else n_seeds // world
         # compulsory HBM bytes of one step on this rank: image read once (1 B/px), every stamp and label written once
         # (4 + 4 B/px), seeds read once (8 B as u32 pairs on the device; SURVEY 8d counts the host's 16 B)
         b_min = npx_rank * 9 + 16 * n_seeds_rank
+        if cfg == "c3":      # + the segmenting labels read once and the union-find parents of the seed colours written once
+            b_min += npx_rank * 4 + 4 * n_seeds_rank
         b_sweep = npx_rank * SWEEP_BYTES_PER_PX + 16 * n_seeds_rank
         compulsory_GBps = b_min / (ms_step * 1e-3) / 1e9
         sweep_equiv = b_sweep / (ms_step * 1e-3) / 1e9
@@ -347,6 +353,8 @@ def run(args):
                 "device_ms_per_step": {k: round(agg[k] / args.steps, 4) for k in ("ms_total", "ms_relax", "ms_resolve", "ms_sweep", "ms_other")},
             })
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if cfg == "c3":
+                roof["note"] += "  (c3: k_relax is the dominant kernel of the merging transform too; the union / relabel part adds ~0.35 ms)"
             if cfg == "headline" and args.engine == "fused" and H == 8192 and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 roof["traffic"] = int(tj["k_relax"]["bytes_per_launch"])
@@ -360,6 +368,19 @@ def run(args):
                          "frac": round(compulsory_GBps / HBM_PEAK_GBS, 5), "traffic": None,
                          "note": "compulsory bytes of this rank's row block over the step time (no per-kernel leg in tiled mode)",
                          "exchange_rounds_per_step": round(sum(rounds_seen) / max(len(rounds_seen), 1), 2)})
+        # the box's own achievable HBM rate (report against both): a 1 GiB device-to-device copy, read + write
+        a = torch.empty(1 << 28, dtype=torch.int32, device=eng.device)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(5):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        copy_GBps = 5 * 2 * a.numel() * 4 / (time.perf_counter() - tc) / 1e9
+        del a, b
+        roof["copy_GBps_measured"] = round(copy_GBps, 1)
+        roof["frac_compulsory_of_copy"] = round(compulsory_GBps / copy_GBps, 5)
         # whole transform against the bytes it cannot avoid -- the honest roofline fraction
         roof["compulsory_bytes_per_step"] = int(b_min)
         roof["compulsory_GBps"] = round(compulsory_GBps, 1)
@@ -371,7 +392,8 @@ def run(args):
                                                  "note": "speed-equivalent of a sweep-per-level engine, not bandwidth"}
         out = {
             "metric": "Mpixels/s segmenting watershed, 8192x8192 u8, device-resident" if cfg == "headline"
-                      else f"Mpixels/s segmenting watershed, BASELINE config {cfg}, device-resident",
+                      else ("Mpixels/s merging watershed (final labels), 8192x8192 u8, BASELINE config c3, device-resident" if cfg == "c3"
+                            else f"Mpixels/s segmenting watershed, BASELINE config {cfg}, device-resident"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8 image / u32 stamps+labels (integer min/max/compare)", "data": "synthetic",

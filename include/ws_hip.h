@@ -289,6 +289,19 @@ int ws_block_export_boundary(ws_ctx *ctx, const uint32_t *d_labels, size_t h, si
 int ws_block_import_boundary(ws_ctx *ctx, const uint32_t *d_table /* world * 2 * w words */, size_t world, size_t rank,
                              uint32_t *d_labels, size_t h, size_t w, int halo_top, int halo_bottom);
 
+/* The MERGING transform's final canonical labels of a tiled field (lib.rs:1328-1522 over row blocks), after the tiled
+ * segmenting transform has left d_labels (halo rows included) final.  d_parent: n_colours_total + 1 words (colour 0 =
+ * uncoloured), a union-find over ALL seed colours of the field, owned by the caller.  row0 = field row of the block's
+ * first local row.  Sequence: ws_block_merge_local; ws_block_merge_export (4 * w (colour, root) pairs: the block's two
+ * boundary rows and its halo rows); all-gather of the pairs; ws_block_merge_import; ws_block_merge_relabel.  One
+ * exchange, no rounds: a lake that spans several blocks is a chain of local pieces linked at boundary colours. */
+int ws_block_merge_local(ws_ctx *ctx, const uint32_t *d_labels, size_t h, size_t w, size_t row0, size_t field_rows,
+                         size_t n_colours_total, uint32_t *d_parent);
+int ws_block_merge_export(ws_ctx *ctx, const uint32_t *d_labels, size_t h, size_t w, uint32_t *d_parent, uint32_t *d_pairs);
+int ws_block_merge_import(ws_ctx *ctx, const uint32_t *d_pairs, size_t n_pairs, uint32_t *d_parent);
+int ws_block_merge_relabel(ws_ctx *ctx, const uint32_t *d_labels, size_t n, uint32_t *d_parent, size_t n_colours_total,
+                           uint32_t *d_out);
+
 /* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
 int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                            uint64_t seed);

@@ -152,4 +152,12 @@ extern "C" {
         halo_bottom: c_int, rank: usize, d_rows: *mut u32) -> c_int;
     pub fn ws_block_import_boundary(ctx: *mut ws_ctx, d_table: *const u32, world: usize, rank: usize, d_labels: *mut u32,
         h: usize, w: usize, halo_top: c_int, halo_bottom: c_int) -> c_int;
+    // ... and the merging transform's final labels across the blocks (one all-gather of boundary (colour, root) pairs)
+    pub fn ws_block_merge_local(ctx: *mut ws_ctx, d_labels: *const u32, h: usize, w: usize, row0: usize, field_rows: usize,
+        n_colours_total: usize, d_parent: *mut u32) -> c_int;
+    pub fn ws_block_merge_export(ctx: *mut ws_ctx, d_labels: *const u32, h: usize, w: usize, d_parent: *mut u32,
+        d_pairs: *mut u32) -> c_int;
+    pub fn ws_block_merge_import(ctx: *mut ws_ctx, d_pairs: *const u32, n_pairs: usize, d_parent: *mut u32) -> c_int;
+    pub fn ws_block_merge_relabel(ctx: *mut ws_ctx, d_labels: *const u32, n: usize, d_parent: *mut u32,
+        n_colours_total: usize, d_out: *mut u32) -> c_int;
 }

@@ -105,6 +105,10 @@ SIGNATURES = {
     "ws_block_resolve_local": (ctypes.c_int, [vp, vp, vp, sz, sz, ctypes.c_int, ctypes.c_int]),
     "ws_block_export_boundary": (ctypes.c_int, [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, sz, vp]),
     "ws_block_import_boundary": (ctypes.c_int, [vp, vp, sz, sz, vp, sz, sz, ctypes.c_int, ctypes.c_int]),
+    "ws_block_merge_local": (ctypes.c_int, [vp, vp, sz, sz, sz, sz, sz, vp]),
+    "ws_block_merge_export": (ctypes.c_int, [vp, vp, sz, sz, vp, vp]),
+    "ws_block_merge_import": (ctypes.c_int, [vp, vp, sz, vp]),
+    "ws_block_merge_relabel": (ctypes.c_int, [vp, vp, sz, vp, sz, vp]),
     "ws_random_field_device": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint64]),
 }
 

@@ -1165,6 +1165,49 @@ int ws_block_import_boundary(ws_ctx *c, const uint32_t *d_table, size_t world, s
   return WS_OK;
 }
 
+// ---- merging transform of a tiled field: final canonical labels (third row) ---------------------------------
+//
+// After the tiled segmenting transform (labels of the block final, halo rows included):
+//   ws_block_merge_local    a union-find over ALL n_colours_total seed colours of the field in the caller's d_parent,
+//                           the block's touching colours joined (ws_merge.hip, k_block_union_pixels)
+//   ws_block_merge_export   (colour, root) of the block's boundary and halo rows: 4 * w pairs
+//   all-gather of the pairs (distributed.py)
+//   ws_block_merge_import   joins every gathered pair
+//   ws_block_merge_relabel  d_out[p] = root(d_labels[p]): the smallest seed colour of the pixel's lake
+int ws_block_merge_local(ws_ctx *c, const uint32_t *d_labels, size_t h, size_t w, size_t row0, size_t field_rows,
+                         size_t n_colours_total, uint32_t *d_parent) {
+  if (!c || !d_labels || !d_parent || row0 + h > field_rows) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || field_rows > 0x7FFFFFF0ull || n_colours_total >= 0x7FFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too large");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->uf_size, (n_colours_total + 1) * sizeof(uint32_t)))) return rc;      // uf_init's second array
+  HIP_TRY(c, uf_init(c->stream, d_parent, (uint32_t *)c->uf_size.p, n_colours_total + 1));
+  HIP_TRY(c, block_union_pixels(c->stream, d_labels, (int)h, (int)w, (int)row0, (int)field_rows, d_parent));
+  return WS_OK;
+}
+
+int ws_block_merge_export(ws_ctx *c, const uint32_t *d_labels, size_t h, size_t w, uint32_t *d_parent, uint32_t *d_pairs) {
+  if (!c || !d_labels || !d_parent || !d_pairs || h == 0) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_colour_roots(c->stream, d_labels, (int)h, (int)w, d_parent, (uint2 *)d_pairs));
+  return WS_OK;
+}
+
+int ws_block_merge_import(ws_ctx *c, const uint32_t *d_pairs, size_t n_pairs, uint32_t *d_parent) {
+  if (!c || !d_parent || (n_pairs && !d_pairs)) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // (0, 0) pairs -- uncoloured boundary pixels -- join colour 0 with itself: nothing happens
+  HIP_TRY(c, union_edges(c->stream, (const uint2 *)d_pairs, n_pairs, d_parent, nullptr, nullptr));
+  return WS_OK;
+}
+
+int ws_block_merge_relabel(ws_ctx *c, const uint32_t *d_labels, size_t n, uint32_t *d_parent, size_t n_colours_total, uint32_t *d_out) {
+  if (!c || !d_parent || (n && (!d_labels || !d_out))) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, relabel_final_u32(c->stream, d_labels, d_parent, n_colours_total + 1, d_out, n));
+  return WS_OK;
+}
+
 // ---- merging (ws_merge.hip) ------------------------------------------------------------------
 
 }  // extern "C"

@@ -359,6 +359,60 @@ hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *siz
   return hipGetLastError();
 }
 
+// ---- merging across the row blocks of a tiled field (third row) -----------------------------------------
+//
+// Final labels only.  Every rank holds a union-find over ALL seed colours of the field and joins the touching colours of
+// its own block: every horizontal pair of its rows and every vertical pair (r, r + 1), seam pairs to its halo rows
+// included, under find_merge's rule that one pixel of a pair is interior IN THE WHOLE FIELD (lib.rs:411-434; `row0` is
+// the field row of the block's first local row).  A lake that spans several blocks is a chain of such local pieces
+// linked at boundary colours, so it is enough that every rank tells every other, for each colour c on its two boundary
+// rows and its halo rows, the root of c in ITS forest: k_block_colour_roots writes the pairs (c, root(c)), one
+// all-gather, and every rank joins all gathered pairs into its own forest (union_edges).  Roots are class minima
+// (union-by-min), so the merged root is the smallest seed colour of the whole lake: the canonical id.
+__global__ __launch_bounds__(256) void k_block_union_pixels(const uint32_t *__restrict__ labels, int h, int w, int row0, int H,
+                                                            uint32_t *parent) {
+  const size_t n = (size_t)h * w;
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; p < n; p += step) {
+    const uint32_t lp = labels[p];
+    if (lp == 0u) continue;                              // at the final level a pixel is coloured iff its label is not 0
+    const int y = (int)(p / (size_t)w), x = (int)(p - (size_t)y * w);
+    const bool ip = interior(row0 + y, x, H, w);
+    if (x + 1 < w) {
+      const uint32_t lq = labels[p + 1];
+      if (lq != 0u && lq != lp && (ip || interior(row0 + y, x + 1, H, w))) (void)uf_union(parent, lp, lq);
+    }
+    if (y + 1 < h) {
+      const uint32_t lq = labels[p + w];
+      if (lq != 0u && lq != lp && (ip || interior(row0 + y + 1, x, H, w))) (void)uf_union(parent, lp, lq);
+    }
+  }
+}
+
+hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent) {
+  if (h == 0 || w == 0) return hipSuccess;
+  const size_t n = (size_t)h * w;
+  k_block_union_pixels<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(labels, h, w, row0, H, parent);
+  return hipGetLastError();
+}
+
+// pairs[i] = (colour, root of colour) for the pixels of local rows 0, 1, h - 2, h - 1 (4 w pairs; (0, 0) where uncoloured)
+__global__ void k_block_colour_roots(const uint32_t *__restrict__ labels, int h, int w, uint32_t *parent, uint2 *pairs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)4 * w) return;
+  const int k = (int)(i / (size_t)w), x = (int)(i - (size_t)k * w);
+  const int rows[4] = {0, min(1, h - 1), max(h - 2, 0), h - 1};
+  const uint32_t c = labels[(size_t)rows[k] * w + x];
+  pairs[i] = c ? make_uint2(c, uf_find(parent, c)) : make_uint2(0u, 0u);
+}
+
+hipError_t block_colour_roots(hipStream_t s, const uint32_t *labels, int h, int w, uint32_t *parent, uint2 *pairs) {
+  if (h == 0 || w == 0) return hipSuccess;
+  k_block_colour_roots<<<(unsigned)((4 * (size_t)w + 255) / 256), 256, 0, s>>>(labels, h, w, parent, pairs);
+  return hipGetLastError();
+}
+
 // ---- final-only path ---------------------------------------------------------------------
 
 // One launch, 64x64 tiles.  Joining every crossing pixel pair in the global forest costs ~60 M

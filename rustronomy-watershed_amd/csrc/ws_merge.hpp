@@ -52,6 +52,12 @@ hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *h
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
                       uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level);
 
+// merging across the row blocks of a tiled field: joins the touching colours of one block (seam pairs to its halo rows
+// included; row0 = field row of the block's first local row, H = rows of the whole field), and the (colour, root) pairs
+// of the block's boundary and halo rows (4 * w of them) that the ranks exchange
+hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent);
+hipError_t block_colour_roots(hipStream_t s, const uint32_t *labels, int h, int w, uint32_t *parent, uint2 *pairs);
+
 // final-only path: union every crossing edge of the whole image in one launch
 // final level only (coloured <=> label != 0); tile_min: union_image_tiles(h, w) words of scratch
 size_t union_image_tiles(int h, int w);

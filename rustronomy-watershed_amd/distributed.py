@@ -135,6 +135,33 @@ class HipBlockEngine:
         """world == 1: the block is the whole field -- the ordinary single-device transform."""
         return self.eng.segment(self.img, self.seeds, max_level=self.max_level, out=self.labels)
 
+    def single_merge(self):
+        return self.eng.merge(self.img, self.seeds, max_level=self.max_level)
+
+    # ---- merging across blocks: final canonical labels -------------------------------------------------------------
+    def merge_local(self, row0, field_rows, n_colours_total):
+        """A union-find over all seed colours of the field, this block's touching colours joined."""
+        self.n_colours_total = int(n_colours_total)
+        self.parent = torch.empty(self.n_colours_total + 1, dtype=torch.int32, device=self.img.device)
+        self._check(_ffi.lib().ws_block_merge_local(self.eng.ctx.handle, self.labels.data_ptr(), self.h, self.w, row0, field_rows,
+                                                    self.n_colours_total, self.parent.data_ptr()))
+
+    def merge_export(self):
+        pairs = torch.empty((4 * self.w, 2), dtype=torch.int32, device=self.img.device)
+        self._check(_ffi.lib().ws_block_merge_export(self.eng.ctx.handle, self.labels.data_ptr(), self.h, self.w,
+                                                     self.parent.data_ptr(), pairs.data_ptr()))
+        return pairs
+
+    def merge_import(self, pairs):
+        pairs = pairs.to(self.img.device).contiguous()
+        self._check(_ffi.lib().ws_block_merge_import(self.eng.ctx.handle, pairs.data_ptr(), pairs.numel() // 2, self.parent.data_ptr()))
+
+    def merge_relabel(self):
+        out = torch.empty_like(self.labels)
+        self._check(_ffi.lib().ws_block_merge_relabel(self.eng.ctx.handle, self.labels.data_ptr(), self.labels.numel(),
+                                                      self.parent.data_ptr(), self.n_colours_total, out.data_ptr()))
+        return out
+
     # ---- general form (any seed list, any width) -------------------------------------------------------------------
     def init(self):
         n = int(self.seeds.shape[0])
@@ -266,3 +293,21 @@ def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
     top = 1 if rank > 0 else 0
     bot = block.labels.shape[0] - (1 if rank < world - 1 else 0)
     return block.labels[top:bot], rounds
+
+
+def merge_tiled(block, rank, world, row0, field_rows, n_colours_total, group=None):
+    """Final canonical labels of the MERGING transform of one field tiled over `world` ranks (lib.rs:1328-1522 after the
+    last level: every lake carries the smallest seed colour in it).  `row0`: field row of the block's first LOCAL row
+    (its halo row, if it has one); `n_colours_total`: seeds of the whole field.  Runs the tiled segmenting transform,
+    joins the touching colours of the block, and exchanges ONE table: the (colour, local root) pairs of every rank's
+    boundary and halo rows (4 x width pairs per rank).  Returns (owned label rows, number of collective exchanges)."""
+    if world == 1:
+        return block.single_merge(), 0
+    _, rounds = segment_tiled(block, rank, world, group)
+    block.merge_local(row0, field_rows, n_colours_total)
+    pairs = _gather_rows(block.merge_export(), world, group)          # (world, 4 w, 2)
+    block.merge_import(pairs.reshape(-1, 2))
+    out = block.merge_relabel()
+    top = 1 if rank > 0 else 0
+    bot = out.shape[0] - (1 if rank < world - 1 else 0)
+    return out[top:bot], rounds + 1

@@ -161,3 +161,55 @@ class NumpyBlockEngine:
         self.relax()
         self.resolve()
         return self.labels
+
+    # ---- merging across blocks (ws_block_merge_*) -------------------------------------------------------------------------
+    def _find(self, x):
+        p = self.parent
+        while p[x] != x:
+            p[x] = p[p[x]]
+            x = p[x]
+        return x
+
+    def _union(self, a, b):
+        a, b = self._find(a), self._find(b)
+        if a != b:
+            self.parent[max(a, b)] = min(a, b)          # union by min: the root is the smallest colour of the class
+
+    def merge_local(self, row0, field_rows, n_colours_total):
+        self.parent = np.arange(n_colours_total + 1, dtype=np.int64)
+        l = self._l().astype(np.int64)
+        rows = row0 + np.arange(self.h)[:, None]
+        cols = np.arange(self.w)[None, :]
+        inter = (rows >= 1) & (rows < field_rows - 1) & (cols >= 1) & (cols < self.w - 1)      # find_merge: lib.rs:411-434
+        a, b, ok = l[:, :-1], l[:, 1:], (inter[:, :-1] | inter[:, 1:])
+        m = (a != 0) & (b != 0) & (a != b) & ok
+        pairs = set(zip(a[m].tolist(), b[m].tolist()))
+        a, b, ok = l[:-1, :], l[1:, :], (inter[:-1, :] | inter[1:, :])
+        m = (a != 0) & (b != 0) & (a != b) & ok
+        pairs |= set(zip(a[m].tolist(), b[m].tolist()))
+        for x, y in pairs:
+            self._union(x, y)
+
+    def merge_export(self):
+        l = self._l().astype(np.int64)
+        rows = [0, min(1, self.h - 1), max(self.h - 2, 0), self.h - 1]
+        out = np.zeros((4 * self.w, 2), dtype=np.int64)
+        for k, r in enumerate(rows):
+            for x in range(self.w):
+                c = int(l[r, x])
+                if c:
+                    out[k * self.w + x] = (c, self._find(c))
+        return torch.from_numpy(out.astype(np.int32))
+
+    def merge_import(self, pairs):
+        for c, r in pairs.numpy().astype(np.int64).reshape(-1, 2):
+            if c:
+                self._union(int(c), int(r))
+
+    def merge_relabel(self):
+        l = self._l().astype(np.int64)
+        roots = np.array([self._find(i) for i in range(len(self.parent))], dtype=np.int64)
+        return torch.from_numpy(roots[l].astype(np.uint32).view(np.int32))
+
+    def single_merge(self):
+        raise NotImplementedError

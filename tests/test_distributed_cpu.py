@@ -112,6 +112,44 @@ def test_tiled_field_more_ranks_than_a_chain_is_long():
         importlib.import_module("rustronomy_watershed_amd.distributed").row_block(3, 0, 4)      # fewer rows than ranks
 
 
+def _merge_worker(rank, world, port, img, seeds, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        from numpy_engine import NumpyBlockEngine
+        r0, r1, lo, hi = wd.row_block(img.shape[0], rank, world)
+        loc, col = wd.local_seeds(seeds.astype(np.int64), lo, hi)
+        block = NumpyBlockEngine(img[lo:hi], loc.numpy(), col.numpy())
+        owned, _ = wd.merge_tiled(block, rank, world, lo, img.shape[0], len(seeds))
+        np.save(os.path.join(outdir, f"merged{rank}.npy"), owned.numpy().view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,kind", [(2, (40, 36), "noise"), (3, (45, 40), "smooth"), (4, (34, 44), "smooth")])
+def test_merging_final_labels_across_row_blocks(world, shape, kind):
+    # the merging transform's final canonical labels (smallest seed colour of every lake) of a tiled field: lakes that
+    # span several blocks, some of them in locally disconnected pieces, against the single-domain oracle
+    img = cases.field(*shape, 11) if kind == "noise" else cases.smooth_field(*shape, 4)
+    seeds = ol.find_local_minima(img)
+    if kind == "smooth":
+        seeds = seeds[::2]
+    # walls (NEVER_FILL columns with gaps) so that not everything ends up in one lake
+    img = img.copy()
+    img[:, shape[1] // 2] = 255
+    img[shape[0] // 3, shape[1] // 2] = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_merge_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), d), nprocs=world, join=True)
+        got = np.concatenate([np.load(os.path.join(d, f"merged{r}.npy")) for r in range(world)], axis=0)
+    want = ol.merge_arrival(img, seeds)
+    assert (got == want).all()
+    assert len(np.unique(want)) >= 2
+
+
 def test_row_blocks_and_slice_sharding_partition_exactly():
     pkg = ge.load_package()
     import importlib

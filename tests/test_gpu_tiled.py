@@ -136,3 +136,42 @@ def test_tiled_hip_three_ranks_smooth_field_and_corridor():
     got, rounds = _run(cor, [(1, 1)], 2)
     assert (got == ol.segment(cor, [(1, 1)])).all()
     assert rounds > 20
+
+
+def _merge_worker(rank, world, port, img, seeds, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        import torch
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        dev = importlib.import_module("rustronomy_watershed_amd.device")
+        eng = dev.DeviceEngine(0)
+        r0, r1, lo, hi = wd.row_block(img.shape[0], rank, world)
+        loc, col = wd.local_seeds(seeds.astype(np.int64), lo, hi)
+        block = wd.HipBlockEngine(eng, torch.from_numpy(img[lo:hi].copy()).cuda(), loc, col)
+        owned, _ = wd.merge_tiled(block, rank, world, lo, img.shape[0], len(seeds))
+        torch.cuda.synchronize()
+        np.save(os.path.join(outdir, f"merged{rank}.npy"), owned.cpu().numpy().view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,kind", [(2, (700, 520), "noise"), (3, (300, 260), "smooth"), (2, (301, 262), "smooth")])
+def test_tiled_hip_merging_final_labels(world, shape, kind):
+    # the merging transform's final canonical labels across row blocks (ws_block_merge_*), against the oracle's
+    # single-domain merging transform; the last case takes the general tiled form (w % 4 != 0)
+    img = cases.field(*shape, 12) if kind == "noise" else cases.smooth_field(*shape, 6)
+    img = img.copy()
+    img[:, shape[1] // 2] = 255                     # a wall with one gap: several lakes survive, some span all blocks
+    img[shape[0] // 3, shape[1] // 2] = 3
+    seeds = ol.find_local_minima(img)
+    ge.build_hip()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_merge_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), d), nprocs=world, join=True)
+        got = np.concatenate([np.load(os.path.join(d, f"merged{r}.npy")) for r in range(world)], axis=0)
+    want = ol.merge_arrival(img, seeds)
+    assert (got == want).all()
+    assert len(np.unique(want)) >= 2
