@@ -45,7 +45,7 @@ struct ws_ctx {
   ws_stats stats{};
 
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
-  DevBuf uf_parent, uf_size, uf_hooked, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
+  DevBuf uf_parent, uf_size, uf_hooked, uf_death, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
@@ -754,7 +754,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->seeds64,
-                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->uf_death, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1249,6 +1249,7 @@ int ensure_uf(ws_ctx *c, size_t n_colours) {
   if ((rc = ensure(c, c->uf_parent, n_colours * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->uf_size, n_colours * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->uf_hooked, n_colours * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(c, c->uf_death, n_colours * sizeof(uint32_t)))) return rc;
   return WS_OK;
 }
 
@@ -1260,15 +1261,24 @@ unsigned level_grid(size_t n_px) { return (unsigned)std::min<size_t>(std::max<si
 //   merging: union this level's crossing edges (lib.rs:1449-1466 in closed form)
 //   want_sizes: keep per-lake areas (lib.rs:628-635)
 //   per_level(l): called after level l is queued (device state current on c->stream)
+//   fused (merging lists without a hook): the records of level l - 1 ride in the launch that joins level l's edges
+//   (k_union_emit; ws_merge.hip) -- two launches per level instead of three; the caller emits the last level
+struct FusedEmit {
+  bool on = false;
+  size_t n_colours = 0, cap = 0;
+  uint64_t *lakes = nullptr;
+};
 template <class F>
-int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_sizes, unsigned grid, F per_level) {
+int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_sizes, unsigned grid, F per_level, const FusedEmit &fe = FusedEmit()) {
   uint32_t *parent = (uint32_t *)c->uf_parent.p, *size = (uint32_t *)c->uf_size.p, *hooked = (uint32_t *)c->uf_hooked.p;
   u64c *mf = (u64c *)c->mflags.p;
   uint32_t *hooked_count = (uint32_t *)(mf + MF_HOOKED);
   const uint32_t *px_items = (const uint32_t *)c->px_items.p;
   const uint2 *edge_items = (const uint2 *)c->edge_items.p;
   for (uint32_t l = l0; l < l1; ++l) {
-    if (merging) HIP_TRY(c, union_edges_ranged(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, want_sizes ? hooked : nullptr, hooked_count + l));
+    if (fe.on) HIP_TRY(c, union_emit(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, hooked, hooked_count + l, (uint32_t *)c->uf_death.p, l,
+                                    size, fe.n_colours, fe.lakes, fe.cap, mf + MF_LAKE_COUNT));
+    else if (merging) HIP_TRY(c, union_edges_ranged(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, want_sizes ? hooked : nullptr, hooked_count + l));
     // areas of the nodes hooked in this level move to their roots, arriving pixels are counted: one launch
     if (want_sizes) HIP_TRY(c, fold_and_add_ranged(c->stream, merging ? hooked : nullptr, hooked_count + l, px_items, mf + MF_OFF_PX + l, grid, parent, size));
     int rc = per_level(l);
@@ -1311,8 +1321,13 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   const uint32_t levels = (uint32_t)opt->max_water_level + 1;
   const unsigned grid = level_grid(n);
 
+  // merging lists without a hook: level l's records are written by the launch that joins level l + 1's edges
+  FusedEmit fe;
+  fe.on = merging && want_list && !cb;
+  fe.n_colours = n_seeds + 1; fe.cap = cap; fe.lakes = (uint64_t *)c->lakes.p;
+  if (fe.on) HIP_TRY(c, hipMemsetAsync(c->uf_death.p, 0xFF, (n_seeds + 1) * sizeof(uint32_t), c->stream));      // every colour a root
   auto per_level = [&](uint32_t l) -> int {
-    if (want_list)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
+    if (want_list && !fe.on)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
       HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_COUNT, l));
     if (cb) {
       if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
@@ -1328,6 +1343,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   // the previous one's shape and buffers replays it as hipGraphs, one per group of LIST_GROUP levels (the groups' record
   // copies still overlap the later groups).  The second such call captures, later ones replay.
   ws_ctx::ListKey key;
+  // (the fused-record mode follows from merging, want_list and cb == null)
   key.merging = merging; key.want_list = want_list; key.levels = levels; key.n_colours = n_seeds + 1; key.n = n; key.cap = cap;
   key.generation = c->buffer_generation;
   const bool graph_able = !cb && c->stream != nullptr && !c->graph_unusable && !c->profiling && n != 0;
@@ -1337,6 +1353,9 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     for (hipGraphExec_t &g : c->list_graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     c->list_graph_key = use_graphs ? key : ws_ctx::ListKey();
   }
+  if (tuning_env("WS_DEBUG_LIST"))
+    std::fprintf(stderr, "[ws] merge_host: merging %d list %d cb %d levels %u colours %zu n %zu cap %zu gen %llu graph_able %d use_graphs %d fused %d\n",
+                 (int)merging, (int)want_list, cb != nullptr, levels, n_seeds + 1, n, cap, (unsigned long long)key.generation, (int)graph_able, (int)use_graphs, (int)fe.on);
   for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
     const uint32_t g1 = std::min(g0 + LIST_GROUP, levels), gi = g0 / LIST_GROUP;
     bool done = false;
@@ -1344,7 +1363,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
       if (!c->list_graphs[gi]) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int lrc = level_range(c, g0, g1, merging, want_list, grid, per_level);
+          const int lrc = level_range(c, g0, g1, merging, want_list, grid, per_level, fe);
           const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
           if (lrc == WS_OK && e2 == hipSuccess && hipGraphInstantiate(&c->list_graphs[gi], graph, nullptr, nullptr, 0) != hipSuccess) c->list_graphs[gi] = nullptr;
           if (graph) (void)hipGraphDestroy(graph);
@@ -1361,9 +1380,15 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
         done = true;
       }
     }
-    if (!done && (rc = level_range(c, g0, g1, merging, want_list, grid, per_level))) return rc;
+    if (!done && (rc = level_range(c, g0, g1, merging, want_list, grid, per_level, fe))) return rc;
     // a marker per group, so that the records of finished levels can travel to the host while later levels are computed
     if (want_list) HIP_TRY(c, hipEventRecord(c->kern_ev[gi], c->stream));
+  }
+  const uint32_t n_groups = (levels + LIST_GROUP - 1) / LIST_GROUP;
+  if (fe.on) {      // the last level's records; and a marker behind them: in this mode a group's last level is complete one launch later
+    HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_COUNT, levels - 1,
+                          (const uint32_t *)c->uf_death.p));
+    HIP_TRY(c, hipEventRecord(c->kern_ev[n_groups], c->stream));
   }
 
   std::vector<uint64_t> bounds(2 * (NLEVELS + 1));
@@ -1374,7 +1399,8 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     size_t copied = 0;
     for (uint32_t g0 = 0; g0 < levels; g0 += LIST_GROUP) {
       const uint32_t g1 = std::min(g0 + LIST_GROUP, levels);
-      HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g0 / LIST_GROUP], 0));
+      // (fused records: group g's last level is written by group g + 1's first launch -- wait for that group's marker)
+      HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->kern_ev[g0 / LIST_GROUP + (fe.on ? 1 : 0)], 0));
       HIP_TRY(c, hipMemcpyAsync(offsets + g0 + 1, mf + MF_LAKE_COUNT + g0, (g1 - g0) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
       if (g0 == 0)      // the bucket bounds were final before the first level: they ride along with the first group
         HIP_TRY(c, hipMemcpyAsync(bounds.data(), mf + MF_OFF_PX, 2 * (NLEVELS + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));

@@ -221,16 +221,26 @@ hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *la
 // ---- per-level union / sizes / emit -----------------------------------------------------
 
 // range (nullable): {first, end} item indices in device memory -- the level's bucket, whose bounds the host never reads
-__global__ void k_union_edges(const uint2 *__restrict__ edges, size_t n, uint32_t *parent, uint32_t *hooked,
-                              uint32_t *hooked_count, const u64c *__restrict__ range) {
+// death (nullable): death[c] = the level at which colour c stopped being a root (0xFFFFFFFF: still one)
+__device__ __forceinline__ void union_body(const uint2 *__restrict__ edges, size_t n, uint32_t *parent, uint32_t *hooked,
+                                           uint32_t *hooked_count, const u64c *__restrict__ range, uint32_t *death, uint32_t level,
+                                           unsigned nblocks) {
   if (range) { edges += range[0]; n = (size_t)(range[1] - range[0]); }
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
+  const size_t step = (size_t)nblocks * blockDim.x;
   for (; i < n; i += step) {
     const uint2 e = edges[i];
     const uint32_t lost = uf_union(parent, e.x, e.y);
-    if (lost != 0xFFFFFFFFu && hooked) hooked[atomicAdd(hooked_count, 1u)] = lost;
+    if (lost != 0xFFFFFFFFu) {
+      if (hooked) hooked[atomicAdd(hooked_count, 1u)] = lost;
+      if (death) death[lost] = level;
+    }
   }
+}
+
+__global__ void k_union_edges(const uint2 *__restrict__ edges, size_t n, uint32_t *parent, uint32_t *hooked,
+                              uint32_t *hooked_count, const u64c *__restrict__ range) {
+  union_body(edges, n, parent, hooked, hooked_count, range, nullptr, 0u, gridDim.x);
 }
 
 hipError_t union_edges(hipStream_t s, const uint2 *edges, size_t n, uint32_t *parent, uint32_t *hooked,
@@ -304,8 +314,11 @@ hipError_t fold_and_add_ranged(hipStream_t s, const uint32_t *hooked, const uint
 // total" protocol that did that needs __threadfence(), which on this part writes the XCD's L2 back -- 24 us per level
 // for a kernel with 5 us of work, 6 of the 11 ms of a 1024^2 transform_to_list.
 constexpr int EMIT_PER_THREAD = 4;      // colours per thread: a workgroup of 256 looks at 1024 colours and asks for ONE ticket range
-__global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
-                                                    uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level) {
+// death (nullable): a colour is a lake of `level` while death[c] > level -- the test that stays true while the NEXT level's
+// unions are already hooking roots (k_union_emit); without it: parent[c] == c.
+__device__ __forceinline__ void emit_body(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
+                                          uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level,
+                                          const uint32_t *__restrict__ death) {
   __shared__ u64c s_base;
   __shared__ uint32_t s_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__
   for (int k = 0; k < EMIT_PER_THREAD; ++k) {
     const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
     area[k] = i < n_colours ? size[i] : 0u;
-    lake[k] = i < n_colours && area[k] != 0u && parent[i] == (uint32_t)i;
+    lake[k] = i < n_colours && area[k] != 0u && (death ? death[i] > level : parent[i] == (uint32_t)i);
     m[k] = __builtin_amdgcn_ballot_w64(lake[k]);
     mine += (uint32_t)__popcll(m[k]);
   }
@@ -351,11 +364,41 @@ __global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__
   }
 }
 
-hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level) {
+__global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
+                                                    uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level,
+                                                    const uint32_t *__restrict__ death) {
+  emit_body(parent, size, n_colours, lakes, cap, level_counts, level, death);
+}
+
+// The unions of level `level` and the lake records of level `level - 1` in ONE launch (merging transform_to_list: two
+// launches per level instead of three).  They do not interfere: the records read the areas (`size`: only the fold
+// kernels write it) and decide "was a lake at level - 1" by death[c] > level - 1, which a union of THIS level -- it sets
+// death[c] = level -- leaves true; the unions touch parent / hooked / death only.
+__global__ __launch_bounds__(256) void k_union_emit(const uint2 *__restrict__ edge_items, const u64c *__restrict__ range, unsigned union_blocks,
+                                                    uint32_t *parent, uint32_t *hooked, uint32_t *hooked_count, uint32_t *death, uint32_t level,
+                                                    const uint32_t *__restrict__ size, size_t n_colours, unsigned emit_blocks,
+                                                    uint64_t *lakes, size_t cap, u64c *level_counts) {
+  if (blockIdx.x < union_blocks) union_body(edge_items, 0, parent, hooked, hooked_count, range, death, level, union_blocks);
+  if (level > 0 && blockIdx.x < emit_blocks) emit_body(parent, size, n_colours, lakes, cap, level_counts, level - 1, death);
+}
+
+static size_t emit_blocks_for(size_t n_colours) {
   const size_t per_block = 256 * EMIT_PER_THREAD;
-  const size_t blocks = n_colours <= 1 ? 1 : (n_colours - 1 + per_block - 1) / per_block;
-  k_emit_lakes<<<(unsigned)blocks, 256, 0, s>>>(parent, size, n_colours, lakes, cap, level_counts, level);
+  return n_colours <= 1 ? 1 : (n_colours - 1 + per_block - 1) / per_block;
+}
+
+hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
+                      uint32_t *hooked_count, uint32_t *death, uint32_t level, const uint32_t *size, size_t n_colours, uint64_t *lakes,
+                      size_t cap, u64c *level_counts) {
+  const unsigned eb = (unsigned)emit_blocks_for(n_colours);
+  k_union_emit<<<std::max(union_grid, level > 0 ? eb : 0u), 256, 0, s>>>(edge_items, range, union_grid, parent, hooked, hooked_count, death, level,
+                                                                        size, n_colours, eb, lakes, cap, level_counts);
+  return hipGetLastError();
+}
+
+hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
+                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level, const uint32_t *death) {
+  k_emit_lakes<<<(unsigned)emit_blocks_for(n_colours), 256, 0, s>>>(parent, size, n_colours, lakes, cap, level_counts, level, death);
   return hipGetLastError();
 }
 

@@ -49,8 +49,15 @@ hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *h
 // appends (colour, area) of every root with area > 0 behind the records of the earlier levels; counts past cap too
 // level_counts: one record counter per level, zero on entry; the records of level l start at the sum of
 // level_counts[0 .. l) (earlier launches) and level_counts[l] receives this level's count
+// death (nullable): per colour, the level at which it stopped being a root (union_emit keeps it); then "lake of `level`"
+// means death[c] > level instead of parent[c] == c
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
-                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level);
+                      uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level, const uint32_t *death = nullptr);
+// the unions of `level` (bucket bounds in device memory) and the lake records of level - 1 in one launch; death: n_colours
+// words, 0xFFFFFFFF at the start
+hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
+                      uint32_t *hooked_count, uint32_t *death, uint32_t level, const uint32_t *size, size_t n_colours, uint64_t *lakes,
+                      size_t cap, u64c *level_counts);
 
 // merging across the row blocks of a tiled field: joins the touching colours of one block (seam pairs to its halo rows
 // included; row0 = field row of the block's first local row, H = rows of the whole field), and the (colour, root) pairs

@@ -264,3 +264,25 @@ def test_merge_final_random_mazes_of_open_and_walled_tiles(pkg):
         got = eng.merge(img, seeds).cpu().numpy().view(np.uint32)
         want = ol.merge_arrival(himg, hseeds)
         assert (got == want).all(), (case, h, w, n_seeds)
+
+
+def test_to_list_call_sequences_on_one_context_replay_the_right_graphs(pkg):
+    # the level loop of transform_to_list / transform_final is replayed as hipGraphs when a call repeats the previous
+    # one's shape; a call of ANOTHER shape (levels, seeds, pixels, capacity) must never replay them.  One context,
+    # shapes interleaved and repeated, every result against the oracle.
+    cases_ = [((72, 88), 9, 1), ((72, 88), 9, 60), ((128, 96), 3, 254), ((72, 88), 9, 60), ((40, 52), 5, 17), ((72, 88), 9, 254)]
+    for shape, seed, maxlvl in cases_:
+        img = cases.field(*shape, seed)
+        seeds = ol.find_local_minima(img)
+        want = []
+        final = ol.merge_arrival(img, seeds, max_level=maxlvl, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(c)))
+        ws = _merging(pkg, max_level=maxlvl)
+        for rep in range(3):                      # 2nd call captures, 3rd replays
+            got = ws.transform_to_list_sparse(img, seeds)
+            assert len(got) == maxlvl + 1
+            for (lvl, unc, cols, areas), w in zip(got, want):
+                nz = np.nonzero(w[1:])[0] + 1
+                assert unc == w[0] and (np.sort(cols) == nz).all() and (areas[np.argsort(cols)] == w[nz]).all(), (shape, maxlvl, rep, lvl)
+            assert (ws.transform_final(img, seeds) == final).all(), (shape, maxlvl, rep)
+            seg = pkg.TransformBuilder.new().set_max_water_lvl(maxlvl).build_segmenting().transform_to_list_sparse(img, seeds)
+            assert sum(int(a.sum()) for _, _, _, a in seg[-1:]) + seg[-1][1] == img.size
