@@ -119,10 +119,15 @@ __device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const u
 // Which tiles of the chunk starting at `first` have to run in this pass?  Lane k answers for tile
 // first + k; the ballot is the to-do list.  tilesX x tilesY is this pass's grid, otherX x otherY the
 // grid of the previous pass.
+// Stamp words of the SAME-GRID passes (below): pass + 1 in the low bits, and
+constexpr uint32_t ST_BORDER = 0x40000000u;      // a border pixel of the tile inside this quadrant changed
+constexpr uint32_t ST_SELF = 0x80000000u;        // (word 0) the tile stopped at its round cap: it goes on itself
+constexpr uint32_t ST_PASS = 0x3FFFFFFFu;
+
 template <int NW>
 __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
                                                          int otherY, int shifted, uint32_t pass,
-                                                         const uint32_t *__restrict__ stamps_prev) {
+                                                         const uint32_t *__restrict__ stamps_prev, int read_same = 0) {
   constexpr int TH = NW * RX_P;
   const int lane = threadIdx.x & 63;
   const int ox = shifted ? RX_TW / 2 : 0, oy = shifted ? TH / 2 : 0;
@@ -131,7 +136,25 @@ __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, 
   const int tx = mine ? t % tilesX : 0, ty = mine ? t / tilesX : 0;
   // a shifted grid can have a last row/column outside the plane
   bool run = mine && tx * RX_TW - ox < W && ty * TH - oy < H;
-  if (pass != 0) {
+  if (read_same) {
+    // Same-grid passes (the long-range regime): the previous pass ran on THIS grid.  A tile runs when it stopped at its
+    // round cap itself, or when a 4-neighbour changed a border pixel on the side facing it -- the two quadrants of the
+    // neighbour that hold that side (quadrant = 2 * lower half + right half).  Exact for the same reason as the
+    // alternating grids: an equation can only be left violated next to a border pixel that changed after it was read.
+    const size_t tt = (size_t)ty * tilesX + tx;
+    const uint32_t s0 = stamps_prev[tt * 4];
+    bool flagged = (s0 & ST_PASS) == pass && (s0 & ST_SELF) != 0u;
+    const int nx[4] = {tx, tx, tx - 1, tx + 1}, ny[4] = {ty - 1, ty + 1, ty, ty};
+    const int qa[4] = {2, 0, 1, 0}, qb[4] = {3, 1, 3, 2};      // up: its bottom quadrants; down: top; left: right; right: left
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = nx[k] >= 0 && nx[k] < tilesX && ny[k] >= 0 && ny[k] < tilesY;
+      const size_t ot = (size_t)(ok ? ny[k] : 0) * tilesX + (ok ? nx[k] : 0);
+      const uint32_t a = stamps_prev[ot * 4 + qa[k]], b = stamps_prev[ot * 4 + qb[k]];
+      flagged |= ok && (((a & ST_PASS) == pass && (a & ST_BORDER) != 0u) || ((b & ST_PASS) == pass && (b & ST_BORDER) != 0u));
+    }
+    run = run && flagged;
+  } else if (pass != 0) {
     // Quadrant (qx, qy) of a tile is quadrant (1-qx, 1-qy) of one tile of the previous pass's grid:
     // did that tile change a border pixel there?  Four independent loads on clamped indices.
     bool flagged = false;
@@ -170,6 +193,7 @@ __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, 
 // length 16 / 64 / 256 px: 16.4 -> 13.1, 29.2 -> 22.2, 12.5 -> 10.7 ms; same passes, shorter ones: gpurun_out/r2e)
 constexpr uint32_t RX_SCAN_AFTER = 0;
 constexpr uint32_t RX_SCAN_FROM_PASS = 4;
+constexpr uint32_t RX_EARLY_ROUND_CAP = 4;     // rounds per tile run in passes 1 .. RX_SCAN_FROM_PASS - 1 (0: no cap): smooth 8192^2, correlation 16 px: 12.4 -> 10.4 ms
 constexpr uint32_t RX_LATE_ROUND_CAP = 2;      // rounds per tile run from pass RX_SCAN_FROM_PASS on (0: no cap); see relax_pass
 
 template <bool TRACK, bool RIGHT>
@@ -255,7 +279,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
-                                                      int pad, uint32_t scan_after, uint32_t *tile_list, int use_list) {
+                                                      int pad, uint32_t scan_after, uint32_t *tile_list, int use_list, int read_same,
+                                                      int write_same) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -293,7 +318,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     n_entries = tile_list[pass & 1u];
     if (entry >= n_entries) return;
   } else if (CHUNKED) {
-    todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
+    todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
     if (todo == 0) return;
   } else {
     const int tx = first % tilesX, ty = first / tilesX;
@@ -580,7 +605,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     e |= 16u;
     // A tile that stopped at the round cap is not a fixpoint of its own pixels: the four tiles of the
     // other grid that cover it re-examine all of it in the next pass.
-    if (unfinished) e |= 15u;
+    // (before a same-grid pass the tile marks ITSELF instead: word 0 of its stamps, below)
+    if (unfinished && !write_same) e |= 15u;
     // bit q: a BORDER pixel of the tile inside quadrant q = 2*(lower half) + (right half) changed
     const uint32_t qbit = 1u << ((band >= NW / 2 ? 2 : 0) + (lane >= 32 ? 1 : 0));
     if (band == 0) {
@@ -598,6 +624,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     }
   }
   if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
+  if (unfinished && write_same) e |= 32u;
   if (e) atomicOr(&s_edges, e);
   __syncthreads();
   if (tid == 0) {
@@ -605,12 +632,19 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     const uint32_t stripe = (blockIdx.x % NSTRIPE) * STRIPE_STRIDE;
     if (ed) {
       const size_t t = (size_t)tile_y * tilesX + tile_x;
-      if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
-      if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
-      if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
-      if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
+      if (write_same) {      // the next pass runs on this grid (relax_todo, read_same)
+        if (ed & 33u) stamps_cur[t * 4 + 0] = (pass + 1) | (ed & 1u ? ST_BORDER : 0u) | (ed & 32u ? ST_SELF : 0u);
+        if (ed & 2u) stamps_cur[t * 4 + 1] = (pass + 1) | ST_BORDER;
+        if (ed & 4u) stamps_cur[t * 4 + 2] = (pass + 1) | ST_BORDER;
+        if (ed & 8u) stamps_cur[t * 4 + 3] = (pass + 1) | ST_BORDER;
+      } else {
+        if (ed & 1u) stamps_cur[t * 4 + 0] = pass + 1;
+        if (ed & 2u) stamps_cur[t * 4 + 1] = pass + 1;
+        if (ed & 4u) stamps_cur[t * 4 + 2] = pass + 1;
+        if (ed & 8u) stamps_cur[t * 4 + 3] = pass + 1;
+      }
       // plain, idempotent stores into striped words: no same-address atomics on the tile path
-      if (ed & 15u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
+      if (ed & 47u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
       pf.any_change[stripe] = 1u;
     }
     if (pf.stats) {            // profiling only: striped counters, one per 64-byte line
@@ -638,14 +672,18 @@ constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
 // smooth map a pass moves the flood fronts by one tile, a few hundred tiles out of thousands, and the chunked launch
 // (a workgroup per four tiles, most of them idle, some with two busy ones to run back to back) took twice as long as
 // the tiles themselves.
+// first pass that runs on the grid of the pass before it (odd; see relax_pass).  8192^2 smooth maps, correlation length
+// 64 / 256 px: 436 -> 260 and 516 -> 292 passes, 16.8 -> 12.6 and 11.0 -> 7.0 ms (gpurun_out/r2k, bit-exact)
+constexpr uint32_t RX_SAME_GRID_FROM = 7;
 constexpr uint32_t RX_LIST_FROM_PASS = 6;      // the bench field has converged by then (its passes 4 and 5 find nothing to do)
 constexpr unsigned RX_LIST_GRID = 1024;
 
 __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, int tilesY, int otherX, int otherY, int shifted,
-                                                    uint32_t pass, const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list) {
+                                                    uint32_t pass, const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list,
+                                                    int read_same) {
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);      // this wave's 64 consecutive tiles
-  const unsigned long long todo = relax_todo<RX_NW>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev);
+  const unsigned long long todo = relax_todo<RX_NW>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
   if (todo == 0) return;
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&tile_list[pass & 1u], (uint32_t)__popcll(todo));
@@ -701,12 +739,21 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const int sh = slice_h > 0 ? slice_h : h;
   const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + th - 1) / th;     // grid anchored at (0, 0): even passes
   const int sx = ax + 1, sy = ay + 1;                                 // grid shifted by half a tile: odd passes
-  const int shifted = (int)(pass & 1u);
+  // Passes from RX_SAME_GRID_FROM on all run on the anchored grid (relax_todo, read_same): in the long-range regime a tile
+  // that stops at its round cap goes on itself, instead of handing its area to the FOUR tiles of the other grid that
+  // cover it (each of which loads 8192 pixels to work on a quarter of them).
+  static const uint32_t same_from = [] {
+    const char *e = tuning_env("WS_RELAX_SAME_GRID_FROM");      // tuning knob, tools/ only
+    const uint32_t v = e ? (uint32_t)atoi(e) : RX_SAME_GRID_FROM;
+    return v < 3u ? 3u : (v | 1u);                               // odd: the pass before it runs on the anchored grid
+  }();
+  const int read_same = pass >= same_from ? 1 : 0, write_same = pass + 1 >= same_from ? 1 : 0;
+  const int shifted = read_same ? 0 : (int)(pass & 1u);
   const int tx = shifted ? sx : ax, ty = shifted ? sy : ay;
   const size_t cap = (size_t)sx * sy * 4;
   const uint32_t *prev = stamps + ((pass + 1) & 1) * cap;
   uint32_t *cur = stamps + (pass & 1) * cap;
-  const int ox_ = shifted ? ax : sx, oy_ = shifted ? ay : sy;        // the previous pass's grid
+  const int ox_ = read_same ? ax : (shifted ? ax : sx), oy_ = read_same ? ay : (shifted ? ay : sy);        // the previous pass's grid
   // Pass 0 only has to produce a good first guess: pass 1 re-examines every pixel on the shifted grid
   // anyway (a capped tile raises all four of its quadrant flags), so its last round -- the one that
   // finds nothing left to do, a third of its time on the bench field -- is not worth running.
@@ -724,6 +771,13 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     return e ? (uint32_t)atoi(e) : RX_LATE_ROUND_CAP;
   }();
   if (pass >= RX_SCAN_FROM_PASS && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
+  // Passes 1 .. 3 have no scans: on a smooth map a tile that iterates to its own fixpoint by sweeps alone takes up to 64
+  // rounds to carry a flood across its 256 columns, all 8192 tiles of them, in a pass that the scan passes then redo.
+  static const uint32_t early_cap = [] {
+    const char *e = tuning_env("WS_RELAX_EARLY_CAP");     // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : RX_EARLY_ROUND_CAP;
+  }();
+  if (pass >= 1 && pass < RX_SCAN_FROM_PASS && early_cap != 0 && early_cap < max_iters) max_iters = early_cap;
   static const uint32_t scan_after = [] {
     const char *e = tuning_env("WS_RELAX_SCAN_AFTER");    // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : RX_SCAN_AFTER;
@@ -741,10 +795,10 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
@@ -754,18 +808,18 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     }();
     if (pass < RX_SCAN_FROM_PASS) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
     } else if (tile_list && pass >= list_from && pass >= RX_SCAN_FROM_PASS + 1) {
       // (the pass before the first list pass has cleared this pass's counter: every kernel variant does, given a list)
-      k_relax_list<<<(unsigned)((tx * ty + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list);
+      k_relax_list<<<(unsigned)((tx * ty + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list, read_same);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
       k_relax<RX_NW, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(tx * ty)), 64 * RX_NW, 0, s>>>(
           img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
-          check_carry, pad, scan_after, tile_list, 1);
+          check_carry, pad, scan_after, tile_list, 1, read_same, write_same);
     } else {
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
     }
   }
   return hipGetLastError();
