@@ -266,19 +266,25 @@ hipError_t union_edges_ranged(hipStream_t s, const uint2 *edge_items, const u64c
 // no longer roots, so no arrival is added to them -- and both add to roots.
 __global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
                                const uint32_t *__restrict__ px_items, size_t n, uint32_t *parent, uint32_t *size,
-                               const u64c *__restrict__ range) {
+                               const u64c *__restrict__ range, int split) {
   if (range) { px_items += range[0]; n = (size_t)(range[1] - range[0]); }
   const int lane = threadIdx.x & 63;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  if (hooked) {
+  // the upper half of the grid folds, the lower half counts arrivals (`split`): two chains of dependent L2 round trips
+  // side by side instead of one after the other
+  const unsigned half = split ? gridDim.x / 2 : gridDim.x;
+  const bool folds = !split || blockIdx.x >= half, counts = !split || blockIdx.x < half;
+  const unsigned bid = split && blockIdx.x >= half ? blockIdx.x - half : blockIdx.x;
+  const size_t step = (size_t)half * blockDim.x;
+  if (hooked && folds) {
     const uint32_t nh = *hooked_count;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nh; i += step) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < nh; i += step) {
       const uint32_t b = hooked[i];
       const uint32_t area = size[b];
       if (area) atomicAdd(&size[uf_find(parent, b)], area);
     }
   }
-  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < n; base += step) {      // uniform trip count per wave
+  if (!counts) return;
+  for (size_t base = (size_t)bid * blockDim.x; base < n; base += step) {      // uniform trip count per wave
     const size_t i = base + threadIdx.x;
     const bool active = i < n;
     const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
@@ -297,13 +303,13 @@ hipError_t fold_and_add(hipStream_t s, const uint32_t *hooked, const uint32_t *h
                         uint32_t *parent, uint32_t *size) {
   if (!hooked && n == 0) return hipSuccess;
   const size_t want = std::max<size_t>((n + 255) / 256, hooked ? 512 : 1);
-  k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size, nullptr);
+  k_fold_and_add<<<(unsigned)std::min<size_t>(want, 4096), 256, 0, s>>>(hooked, hooked_count, px_items, n, parent, size, nullptr, 0);
   return hipGetLastError();
 }
 
 hipError_t fold_and_add_ranged(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items,
                                const u64c *range, unsigned grid, uint32_t *parent, uint32_t *size) {
-  k_fold_and_add<<<grid, 256, 0, s>>>(hooked, hooked_count, px_items, 0, parent, size, range);
+  k_fold_and_add<<<hooked ? 2 * grid : grid, 256, 0, s>>>(hooked, hooked_count, px_items, 0, parent, size, range, hooked ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -318,7 +324,7 @@ constexpr int EMIT_PER_THREAD = 4;      // colours per thread: a workgroup of 25
 // unions are already hooking roots (k_union_emit); without it: parent[c] == c.
 __device__ __forceinline__ void emit_body(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
                                           uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level,
-                                          const uint32_t *__restrict__ death) {
+                                          const uint32_t *__restrict__ death, unsigned bid) {
   __shared__ u64c s_base;
   __shared__ uint32_t s_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,7 +336,7 @@ __device__ __forceinline__ void emit_body(const uint32_t *__restrict__ parent, c
   }
   // same-address atomics retire one per ~10 ns: a ticket request per wave (1.8 k per level at 1024^2) was 17 us of this
   // kernel; per workgroup of 1024 colours it is ~1 us
-  const size_t i0 = (size_t)blockIdx.x * (256 * EMIT_PER_THREAD) + 1;      // colour 0 = uncoloured
+  const size_t i0 = (size_t)bid * (256 * EMIT_PER_THREAD) + 1;      // colour 0 = uncoloured
   uint32_t area[EMIT_PER_THREAD];
   bool lake[EMIT_PER_THREAD];
   unsigned long long m[EMIT_PER_THREAD];
@@ -367,7 +373,7 @@ __device__ __forceinline__ void emit_body(const uint32_t *__restrict__ parent, c
 __global__ __launch_bounds__(256) void k_emit_lakes(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ size, size_t n_colours,
                                                     uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level,
                                                     const uint32_t *__restrict__ death) {
-  emit_body(parent, size, n_colours, lakes, cap, level_counts, level, death);
+  emit_body(parent, size, n_colours, lakes, cap, level_counts, level, death, blockIdx.x);
 }
 
 // The unions of level `level` and the lake records of level `level - 1` in ONE launch (merging transform_to_list: two
@@ -378,8 +384,11 @@ __global__ __launch_bounds__(256) void k_union_emit(const uint2 *__restrict__ ed
                                                     uint32_t *parent, uint32_t *hooked, uint32_t *hooked_count, uint32_t *death, uint32_t level,
                                                     const uint32_t *__restrict__ size, size_t n_colours, unsigned emit_blocks,
                                                     uint64_t *lakes, size_t cap, u64c *level_counts) {
+  // different workgroups for the two jobs: both are chains of dependent L2 round trips (find, find, CAS / load, ticket,
+  // store), and one workgroup doing one after the other took the sum of the two latencies (8.8 us per launch)
   if (blockIdx.x < union_blocks) union_body(edge_items, 0, parent, hooked, hooked_count, range, death, level, union_blocks);
-  if (level > 0 && blockIdx.x < emit_blocks) emit_body(parent, size, n_colours, lakes, cap, level_counts, level - 1, death);
+  else if (level > 0 && blockIdx.x - union_blocks < emit_blocks)
+    emit_body(parent, size, n_colours, lakes, cap, level_counts, level - 1, death, blockIdx.x - union_blocks);
 }
 
 static size_t emit_blocks_for(size_t n_colours) {
@@ -391,7 +400,7 @@ hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range,
                       uint32_t *hooked_count, uint32_t *death, uint32_t level, const uint32_t *size, size_t n_colours, uint64_t *lakes,
                       size_t cap, u64c *level_counts) {
   const unsigned eb = (unsigned)emit_blocks_for(n_colours);
-  k_union_emit<<<std::max(union_grid, level > 0 ? eb : 0u), 256, 0, s>>>(edge_items, range, union_grid, parent, hooked, hooked_count, death, level,
+  k_union_emit<<<union_grid + (level > 0 ? eb : 0u), 256, 0, s>>>(edge_items, range, union_grid, parent, hooked, hooked_count, death, level,
                                                                         size, n_colours, eb, lakes, cap, level_counts);
   return hipGetLastError();
 }
