@@ -289,13 +289,16 @@ __global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32
     const bool active = i < n;
     const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
-    while (todo != 0) {
+    // a few rounds of leader election catch the case that matters (late levels: a handful of lakes, thousands of lanes on
+    // the same word); what is left after them -- early levels: every lane another lake -- adds for itself
+    for (int round = 0; round < 4 && todo != 0; ++round) {
       const int leader = (int)__builtin_ctzll(todo);
       const uint32_t r0 = __shfl(r, leader, 64);
       const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
       if (lane == leader) atomicAdd(&size[r0], (uint32_t)__popcll(same));
       todo &= ~same;
     }
+    if ((todo >> lane) & 1ull) atomicAdd(&size[r], 1u);
   }
 }
 
