@@ -550,3 +550,35 @@ def test_segment_batch_stacked_with_an_unsorted_list_does_not_chase_garbage(pkg)
         got = _run_batch(eng, himgs, sorted_lists)
         for k in range(3):
             assert (got[k] == ol.segment_arrival(himgs[k], sorted_lists[k].astype(np.uint64))).all(), k
+
+
+@pytest.mark.parametrize("shape,octaves", [((1000, 1300), 6), ((777, 1001), 6), ((1500, 640), 7), ((2100, 300), 5)])
+def test_long_range_passes_on_one_grid_odd_shapes(pkg, shape, octaves):
+    # the late passes (compacted tile lists from pass 6, ONE grid from pass 7, round caps) on shapes whose last tile row /
+    # column is partial, on a width that is not a multiple of 4 (scalar loads), and on a tall narrow plane; few seeds, so
+    # that single floods cross the whole plane, and all maxima, so that hundreds of fronts meet
+    img = cases.smooth_field(*shape, 23, octaves=octaves)
+    allseeds = ol.find_local_minima(img)
+    ws = _seg(pkg, pkg.ENGINE_FUSED)
+    for seeds in (allseeds[:: max(len(allseeds) // 3, 1)][:3], allseeds):
+        got = ws.transform(img, seeds)
+        want = ol.segment_arrival(img, seeds)
+        assert got.shape == want.shape and (got == want).all(), (shape, len(seeds))
+        assert ws._ctx().stats()["relax_passes"] >= 8
+    # the same through the merging transform (final labels) and with a low maximum level (large never-flooded regions)
+    mg = pkg.TransformBuilder.new().set_max_water_lvl(120).build_merging()
+    assert (mg.transform_final(img, allseeds) == ol.merge_arrival(img, allseeds, max_level=120)).all()
+
+
+def test_long_range_stacked_slices(pkg):
+    # a stack of smooth slices: hundreds of passes with slice walls inside the tiles of the one-grid passes
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    himgs = [cases.smooth_field(200, 512, 60 + k, octaves=6) for k in range(3)]
+    hseeds = [ol.find_local_minima(a)[:: 5] for a in himgs]
+    got = _run_batch(eng, himgs, hseeds)
+    assert eng.stats()["relax_passes"] >= 8
+    for k in range(3):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
