@@ -471,6 +471,13 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   for (int r = 0; r < RX_P; ++r)
 #pragma unroll
     for (int c = 0; c < RX_P; ++c) B[r][c] = min(B[r][c], T[r][c]);
+  // The columns left / right of the patch, one register per patch row, PERSISTENT: a sweep refreshes them with one DPP
+  // wave shift each, whose `old` operand is the register itself -- lane 0 (lane 63) has no neighbour lane and keeps what
+  // it holds, the tile's halo column, for the whole tile run.  (Passing the halo as `old` every time cost a v_mov per
+  // shift to set the destination up: 16 of the ~80 vector instructions of a sweep.)
+  uint32_t Lh[RX_P], Rh[RX_P];
+#pragma unroll
+  for (int r = 0; r < RX_P; ++r) { Lh[r] = halo[r]; Rh[r] = halo[r]; }
   {
     if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][lane * RX_P]) = halo_row;
     if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NW + 1][lane * RX_P]) = halo_row;
@@ -505,7 +512,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // the three free sweeps of a round, then the band boundary rows are published
   auto free_sweeps = [&](uint32_t round) {
     bool untracked = false;
-    uint32_t up[RX_P], dn[RX_P], L[RX_P], R[RX_P];
+    uint32_t up[RX_P], dn[RX_P];
     {
       const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
       const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
@@ -513,23 +520,23 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
     }
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-    sweep_rows<false, true>(T, B, up, dn, L, R, untracked);       // down
+    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
+    sweep_rows<false, true>(T, B, up, dn, Lh, Rh, untracked);       // down
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-    sweep_cols<false, true>(T, B, up, dn, L, R, untracked);       // right
+    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
+    sweep_cols<false, true>(T, B, up, dn, Lh, Rh, untracked);       // right
     const bool long_range = SCAN && round > scan_after;           // workgroup uniform
     if (long_range) {
 #pragma unroll
-      for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(halo[r], 0, 64), lane, untracked);
+      for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(Lh[r], 0, 64), lane, untracked);
       scan_cols<NW, true>(T, B, &sFn[0][0][0], sRow[0], band, lane);
     }
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-    sweep_rows<false, false>(T, B, up, dn, L, R, untracked);      // up
+    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
+    sweep_rows<false, false>(T, B, up, dn, Lh, Rh, untracked);      // up
     if (long_range) {
 #pragma unroll
-      for (int r = 0; r < RX_P; ++r) scan_row<false, false>(T[r], B[r], __shfl(halo[r], 63, 64), lane, untracked);
+      for (int r = 0; r < RX_P; ++r) scan_row<false, false>(T[r], B[r], __shfl(Rh[r], 63, 64), lane, untracked);
       scan_cols<NW, false>(T, B, &sFn[0][0][0], sRow[2 * NW + 1], band, lane);
     }
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
@@ -543,7 +550,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     ++iters;
     if (!LITE) free_sweeps(iters);
     bool changed = false;
-    uint32_t up[RX_P], dn[RX_P], L[RX_P], R[RX_P];
+    uint32_t up[RX_P], dn[RX_P];
     {
       const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
       const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
@@ -551,8 +558,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
     }
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { L[r] = lane_left(halo[r], T[r][3]); R[r] = lane_right(halo[r], T[r][0]); }
-    sweep_cols<true, false>(T, B, up, dn, L, R, changed);         // left, checked
+    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
+    sweep_cols<true, false>(T, B, up, dn, Lh, Rh, changed);         // left, checked
     const uint32_t slot = (iters - 1) % 3;
     if (__builtin_amdgcn_ballot_w64(changed) != 0) {
       // a neighbour band reads these rows only if another round follows, i.e. only if someone changed
