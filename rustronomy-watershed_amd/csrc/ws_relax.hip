@@ -777,14 +777,19 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     const char *e = tuning_env("WS_RELAX_LATE_CAP");      // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : RX_LATE_ROUND_CAP;
   }();
-  if (pass >= RX_SCAN_FROM_PASS && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
+  static const uint32_t scan_from_knob = [] {
+    const char *e = tuning_env("WS_RELAX_SCAN_FROM");     // tuning knob, tools/ only
+    return e ? (uint32_t)atoi(e) : RX_SCAN_FROM_PASS;
+  }();
+  const uint32_t scan_from = std::max(scan_from_knob, 1u);
+  if (pass >= scan_from && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
   // Passes 1 .. 3 have no scans: on a smooth map a tile that iterates to its own fixpoint by sweeps alone takes up to 64
   // rounds to carry a flood across its 256 columns, all 8192 tiles of them, in a pass that the scan passes then redo.
   static const uint32_t early_cap = [] {
     const char *e = tuning_env("WS_RELAX_EARLY_CAP");     // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : RX_EARLY_ROUND_CAP;
   }();
-  if (pass >= 1 && pass < RX_SCAN_FROM_PASS && early_cap != 0 && early_cap < max_iters) max_iters = early_cap;
+  if (pass >= 1 && pass < scan_from && early_cap != 0 && early_cap < max_iters) max_iters = early_cap;
   static const uint32_t scan_after = [] {
     const char *e = tuning_env("WS_RELAX_SCAN_AFTER");    // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : RX_SCAN_AFTER;
@@ -813,10 +818,10 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
       const char *e = tuning_env("WS_RELAX_LIST_FROM");      // tuning knob, tools/ only
       return e ? (uint32_t)atoi(e) : RX_LIST_FROM_PASS;
     }();
-    if (pass < RX_SCAN_FROM_PASS) {
+    if (pass < scan_from) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
                                                               pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
-    } else if (tile_list && pass >= list_from && pass >= RX_SCAN_FROM_PASS + 1) {
+    } else if (tile_list && pass >= list_from && pass >= scan_from + 1) {
       // (the pass before the first list pass has cleared this pass's counter: every kernel variant does, given a list)
       k_relax_list<<<(unsigned)((tx * ty + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list, read_same);
       hipError_t e = hipGetLastError();
