@@ -206,20 +206,23 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
   hi = med3u(b1, hi + 1u, t1); hi = med3u(b2, hi + 1u, t2); hi = med3u(b3, hi + 1u, t3);
   uint32_t lo = b0;
   lo = med3u(b1, lo + 1u, t1); lo = med3u(b2, lo + 1u, t2); lo = med3u(b3, lo + 1u, t3);
-  uint32_t add = RX_P;
+  // Every lane adds the same RX_P to what passes through it, so in the coordinate W = v + RX_P * (lanes still to go, this
+  // one included) a lane is a PURE clamp [lo + bias, hi + bias], and clamps compose by two medians -- no running sum to
+  // carry through the scan, no additions inside it (r2: a third fewer instructions per step, two shuffles instead of three)
+  const uint32_t bias = RIGHT ? (uint32_t)(RX_P * (63 - lane)) : (uint32_t)(RX_P * lane);
+  lo += bias;
+  hi += bias;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {       // inclusive scan in sweep order: acc_i <- acc_i o acc_(i -/+ o)
     const uint32_t plo = RIGHT ? __shfl_up(lo, o, 64) : __shfl_down(lo, o, 64);
     const uint32_t phi = RIGHT ? __shfl_up(hi, o, 64) : __shfl_down(hi, o, 64);
-    const uint32_t padd = RIGHT ? __shfl_up(add, o, 64) : __shfl_down(add, o, 64);
     const bool has = RIGHT ? lane >= o : lane + o < 64;
-    const uint32_t nlo = med3u(lo, plo + add, hi), nhi = med3u(lo, phi + add, hi);
+    const uint32_t nlo = med3u(lo, plo, hi), nhi = med3u(lo, phi, hi);      // the earlier clamp, then this one
     lo = has ? nlo : lo;
     hi = has ? nhi : hi;
-    add = has ? add + padd : add;
   }
   // the value that leaves this lane when `halo_in` enters the row, handed to the next lane
-  const uint32_t leaves = med3u(lo, halo_in + add, hi);
+  const uint32_t leaves = med3u(lo, halo_in + (uint32_t)(RX_P * 64), hi) - bias;
   const uint32_t vin = RIGHT ? lane_left(halo_in, leaves) : lane_right(halo_in, leaves);
   const uint32_t n0 = med3u(b0, vin + 1u, t0), n1 = med3u(b1, n0 + 1u, t1), n2 = med3u(b2, n1 + 1u, t2), n3 = med3u(b3, n2 + 1u, t3);
   if (TRACK) changed |= (n0 != t0) | (n1 != t1) | (n2 != t2) | (n3 != t3);
