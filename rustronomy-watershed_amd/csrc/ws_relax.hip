@@ -283,7 +283,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
                                                       int pad, uint32_t scan_after, uint32_t *tile_list, int use_list, int read_same,
-                                                      int write_same) {
+                                                      int write_same, uint32_t list_cap, int append_next) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
   constexpr int TH = NW * RX_P;
@@ -307,7 +307,10 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   if (blockIdx.x == 0 && threadIdx.x < NSTRIPE)
     pf.edge_changed[((pass + 1) % COUNTER_RING) * FLAG_SLOT + threadIdx.x * STRIPE_STRIDE] = 0;
   // ... and the length of the next pass's tile list (k_relax_list appends to it after this launch has ended)
-  if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) tile_list[(pass + 1) & 1u] = 0u;
+  // (tile_list: [0..3] list lengths of pass & 3; [4 ...) entries of the even passes, then of the odd ones, then one
+  // "queued for pass" word per tile.  This launch reads the list of `pass`, may append to the list of pass + 1, and clears
+  // the length that pass + 2 will count up from.)
+  if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) tile_list[(pass + 2) & 3u] = 0u;
   // (XCD-aware: consecutive workgroups go to different XCDs; see xcd_span_index)
   // A chunk is `chunk` tiles one grid size apart, not neighbours: on a smooth map the tiles that still
   // run line up along a front, and four neighbours in one workgroup ran one after the other.
@@ -318,7 +321,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // entries b, b + gridDim.x, ... -- no workgroup is launched for a tile that has nothing to do, none owns two busy ones
   uint32_t entry = blockIdx.x, n_entries = 0;
   if (CHUNKED && use_list) {
-    n_entries = tile_list[pass & 1u];
+    n_entries = tile_list[pass & 3u];
     if (entry >= n_entries) return;
   } else if (CHUNKED) {
     todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
@@ -346,7 +349,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   int tid = threadIdx.x;
   if (CHUNKED) asm volatile("" : "+v"(tid));
   const int lane = tid & 63, band = tid >> 6;
-  const int tile = CHUNKED ? (use_list ? (int)tile_list[2 + entry] : first + (int)__builtin_ctzll(todo) * stride) : first;
+  const int tile = CHUNKED ? (use_list ? (int)tile_list[4 + (pass & 1u) * list_cap + entry] : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = tile_x * RX_TW - (shifted ? RX_TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
@@ -655,6 +658,31 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       }
       // plain, idempotent stores into striped words: no same-address atomics on the tile path
       if (ed & 47u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
+      if (append_next) {
+        // The next pass's tile list, written by the tiles that cause its entries (no k_relax_list launch between two
+        // passes: 5 us of every ~45).  The same rule as relax_todo's same-grid test, from the other side: the neighbour
+        // above sees my upper quadrants (0, 1), the one below my lower ones (2, 3), left 0 and 2, right 1 and 3; I go on
+        // myself if I stopped at the round cap.  A word per tile ("queued for pass p") keeps a tile from entering twice:
+        // five independent exchanges on clamped slots (slot list_cap is a dummy), then ONE ticket for the new entries.
+        uint32_t *queued = tile_list + 4 + 2 * (size_t)list_cap;
+        uint32_t *next = tile_list + 4 + ((pass + 1) & 1u) * (size_t)list_cap;
+        const uint32_t mark = pass + 1;
+        const bool want[5] = {(ed & 32u) != 0u, (ed & 3u) != 0u && tile_y > 0, (ed & 12u) != 0u && tile_y + 1 < tilesY,
+                              (ed & 5u) != 0u && tile_x > 0, (ed & 10u) != 0u && tile_x + 1 < tilesX};
+        const uint32_t who[5] = {(uint32_t)t, (uint32_t)(t - tilesX), (uint32_t)(t + tilesX), (uint32_t)(t - 1), (uint32_t)(t + 1)};
+        uint32_t old[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) old[k] = atomicExch(&queued[want[k] ? who[k] : list_cap], mark);
+        uint32_t fresh = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) fresh += (want[k] && old[k] != mark) ? 1u : 0u;
+        if (fresh) {
+          uint32_t at = atomicAdd(&tile_list[(pass + 1) & 3u], fresh);
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (want[k] && old[k] != mark) next[at++] = who[k];
+        }
+      }
       pf.any_change[stripe] = 1u;
     }
     if (pf.stats) {            // profiling only: striped counters, one per 64-byte line
@@ -677,7 +705,9 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 
 constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
 
-// The tiles that have to run in `pass`, compacted: tile_list[pass & 1] = how many, tile_list[2 ...] = which (any order).
+// The tiles that have to run in `pass`, compacted: tile_list[pass & 3] = how many, entries from tile_list[4 + (pass & 1) *
+// list_cap] on (any order).  It also clears the tiles' "queued for pass" words, which the passes that append their
+// successors' lists themselves (k_relax, append_next) exchange: every transform that reaches those passes comes through here.
 // Same test as relax_todo; one atomicAdd per wave that found any.  Worth its own launch only when few tiles run: on a
 // smooth map a pass moves the flood fronts by one tile, a few hundred tiles out of thousands, and the chunked launch
 // (a workgroup per four tiles, most of them idle, some with two busy ones to run back to back) took twice as long as
@@ -690,19 +720,21 @@ constexpr unsigned RX_LIST_GRID = 1024;
 
 __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, int tilesY, int otherX, int otherY, int shifted,
                                                     uint32_t pass, const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list,
-                                                    int read_same) {
+                                                    int read_same, uint32_t list_cap) {
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);      // this wave's 64 consecutive tiles
+  if ((uint32_t)(first + lane) <= list_cap) tile_list[4 + 2 * (size_t)list_cap + first + lane] = 0u;      // queued marks (and the dummy slot)
   const unsigned long long todo = relax_todo<RX_NW>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
   if (todo == 0) return;
   uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&tile_list[pass & 1u], (uint32_t)__popcll(todo));
+  if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
   base = __shfl(base, 0, 64);
-  if ((todo >> lane) & 1ull) tile_list[2 + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
+  if ((todo >> lane) & 1ull)
+    tile_list[4 + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
 }
 
 // words of scratch relax_pass wants for its tile lists
-size_t relax_list_words(int h, int w) { return 2 + relax_tiles(h, w); }
+size_t relax_list_words(int h, int w) { return 4 + 3 * relax_tiles(h, w) + 64; }      // lengths, two entry arrays, queued marks (+ dummy)
 
 // capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column
 size_t relax_tiles(int h, int w) {
@@ -758,6 +790,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     return v < 3u ? 3u : (v | 1u);                               // odd: the pass before it runs on the anchored grid
   }();
   const int read_same = pass >= same_from ? 1 : 0, write_same = pass + 1 >= same_from ? 1 : 0;
+  const uint32_t list_cap = (uint32_t)((size_t)sx * sy);      // = relax_tiles(h, w): entries per tile list
   const int shifted = read_same ? 0 : (int)(pass & 1u);
   const int tx = shifted ? sx : ax, ty = shifted ? sy : ay;
   const size_t cap = (size_t)sx * sy * 4;
@@ -810,10 +843,10 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
@@ -823,18 +856,27 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     }();
     if (pass < scan_from) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
     } else if (tile_list && pass >= list_from && pass >= scan_from + 1) {
-      // (the pass before the first list pass has cleared this pass's counter: every kernel variant does, given a list)
-      k_relax_list<<<(unsigned)((tx * ty + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list, read_same);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return e;
+      // (two passes earlier a launch has cleared this pass's counter: every kernel variant does, given a list)
+      // From the second same-grid pass on the list is there already: the tiles of the pass before appended it.
+      static const bool no_append = tuning_env("WS_RELAX_NO_APPEND") != nullptr;      // A/B knob, tools/ only
+      const uint32_t first_list_pass = std::max(list_from, scan_from + 1);
+      const int append_next = !no_append && pass >= same_from && pass >= first_list_pass ? 1 : 0;
+      const bool appended = !no_append && pass >= 1 && pass - 1 >= same_from && pass - 1 >= first_list_pass;
+      if (!appended) {
+        // (one thread per tile and a few more: the queued marks, dummy slot included, are cleared here)
+        k_relax_list<<<(unsigned)((std::max<size_t>((size_t)tx * ty, list_cap + 1) + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev,
+                                                                                                         tile_list, read_same, list_cap);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
       k_relax<RX_NW, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(tx * ty)), 64 * RX_NW, 0, s>>>(
           img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
-          check_carry, pad, scan_after, tile_list, 1, read_same, write_same);
+          check_carry, pad, scan_after, tile_list, 1, read_same, write_same, list_cap, append_next);
     } else {
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
     }
   }
   return hipGetLastError();
