@@ -238,6 +238,11 @@ int ws_merge_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_
 int ws_last_arrival_device(ws_ctx *ctx, const uint32_t **d_keys, size_t *h, size_t *w);
 /* Copies those stamps into the caller's device buffer of n_elems >= h*w words (stream ordered). */
 int ws_copy_last_arrival_device(ws_ctx *ctx, uint32_t *d_dst, size_t n_elems);
+/* transform_history on the device, one level at a time (lib.rs:1824-1835 without the 255 host copies): the SEGMENTING
+ * label plane as the reference's hook sees it after `water_level` (lib.rs:1796-1804) -- a pixel carries its final colour
+ * once its arrival level is <= water_level, 0 before -- from d_labels (what the last ws_segment_device on this context
+ * wrote) and the context's arrival stamps; d_out is a plane of the same shape (may equal d_labels).  Stream ordered. */
+int ws_level_snapshot_device(ws_ctx *ctx, const uint32_t *d_labels, uint8_t water_level, uint32_t *d_out);
 
 /* ---- input preparation (first "next" row) ---------------------------------------
  *

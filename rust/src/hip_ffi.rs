@@ -129,6 +129,7 @@ extern "C" {
         d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
     pub fn ws_last_arrival_device(ctx: *mut ws_ctx, d_keys: *mut *const u32, h: *mut usize, w: *mut usize) -> c_int;
     pub fn ws_copy_last_arrival_device(ctx: *mut ws_ctx, d_dst: *mut u32, n_elems: usize) -> c_int;
+    pub fn ws_level_snapshot_device(ctx: *mut ws_ctx, d_labels: *const u32, water_level: u8, d_out: *mut u32) -> c_int;
     pub fn ws_pre_processor_device(ctx: *mut ws_ctx, d_data: *const c_void, dtype: c_int, n_elems: usize,
         max_value: u8, d_out: *mut u8) -> c_int;
     pub fn ws_random_field_device(ctx: *mut ws_ctx, d_img: *mut u8, h: usize, w: usize, row_stride: usize,

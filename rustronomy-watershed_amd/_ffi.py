@@ -95,6 +95,7 @@ SIGNATURES = {
     "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_last_arrival_device": (ctypes.c_int, [vp, ctypes.POINTER(vp), szp, szp]),
     "ws_copy_last_arrival_device": (ctypes.c_int, [vp, vp, sz]),
+    "ws_level_snapshot_device": (ctypes.c_int, [vp, vp, ctypes.c_uint8, vp]),
     "ws_pre_processor": (ctypes.c_int, [vp, vp, ctypes.c_int, sz, ctypes.c_uint8, vp]),
     "ws_pre_processor_device": (ctypes.c_int, [vp, vp, ctypes.c_int, sz, ctypes.c_uint8, vp]),
     "ws_block_init": (ctypes.c_int, [vp, sz, sz, vp, vp, sz, vp, vp]),

@@ -905,6 +905,14 @@ int ws_copy_last_arrival_device(ws_ctx *c, uint32_t *d_dst, size_t n_elems) {
   return WS_OK;
 }
 
+int ws_level_snapshot_device(ws_ctx *c, const uint32_t *d_labels, uint8_t water_level, uint32_t *d_out) {
+  if (!c || !d_labels || !d_out) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call was not a fused-engine ws_segment_device / ws_merge_device");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, snapshot_level_u32(c->stream, (const uint32_t *)c->keys.p, d_labels, d_out, c->last_h * c->last_w, water_level));
+  return WS_OK;
+}
+
 int ws_random_field_device(ws_ctx *c, uint8_t *d_img, size_t h, size_t w, size_t stride, uint64_t seed) {
   if (!c || (!d_img && h * w) || stride < w) return fail(c, WS_ERR_BAD_ARG, "bad argument");
   if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull) return fail(c, WS_ERR_TOO_LARGE, "too large");

@@ -94,6 +94,7 @@ hipError_t shift_seeds(hipStream_t s, const uint32_t *src, size_t n, uint32_t sh
 hipError_t widen_labels(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n);
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level);
+hipError_t snapshot_level_u32(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint32_t *dst, size_t n, uint32_t level);
 
 // relaxation (ws_relax.hip): 4x4 register patches, 256 x 32 tiles, row/column sweeps
 size_t relax_tiles(int h, int w);

@@ -497,6 +497,23 @@ __global__ void k_snapshot(const uint32_t *keys, const uint32_t *labels, uint64_
   }
 }
 
+// the same into a u32 plane on the device (ws_level_snapshot_device): 16-byte accesses where the planes allow
+__global__ void k_snapshot_u32(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels, uint32_t *dst, size_t n, uint32_t level) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const uint32_t k = keys[i];
+    dst[i] = (k != KEY_INF && (k >> 24) <= level) ? labels[i] : 0u;
+  }
+}
+
+hipError_t snapshot_level_u32(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint32_t *dst, size_t n, uint32_t level) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 16384 ? (n + 1023) / 1024 : 16384);
+  k_snapshot_u32<<<blocks, 256, 0, s>>>(keys, labels, dst, n, level);
+  return hipGetLastError();
+}
+
 hipError_t snapshot_level(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint64_t *dst,
                           size_t n, uint32_t level) {
   if (n == 0) return hipSuccess;

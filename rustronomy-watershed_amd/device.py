@@ -98,5 +98,12 @@ class DeviceEngine:
         self.ctx.check(_ffi.lib().ws_copy_last_arrival_device(self.ctx.handle, out.data_ptr(), out.numel()))
         return out
 
+    def level_snapshot(self, labels, water_level, out=None):
+        """The segmenting label plane after `water_level` (transform_history's entry for that level), on the device."""
+        if out is None:
+            out = torch.empty_like(labels)
+        self.ctx.check(_ffi.lib().ws_level_snapshot_device(self.ctx.handle, labels.data_ptr(), int(water_level), out.data_ptr()))
+        return out
+
     def stats(self):
         return self.ctx.stats()

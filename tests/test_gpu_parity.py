@@ -582,3 +582,20 @@ def test_long_range_stacked_slices(pkg):
     assert eng.stats()["relax_passes"] >= 8
     for k in range(3):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+
+
+def test_level_snapshots_on_the_device_match_transform_history(pkg):
+    # ws_level_snapshot_device: the plane transform_history reports for a level, without leaving the device
+    import torch
+    eng = _torch_engine(pkg)
+    himg = cases.smooth_field(150, 212, 8)
+    hseeds = ol.find_local_minima(himg)
+    levels = {}
+    ol.segment(himg, hseeds, hook=lambda lvl, mx, im, lab: levels.__setitem__(lvl, lab.copy()))
+    img = torch.from_numpy(himg).to(eng.device)
+    seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(eng.device).contiguous()
+    labels = eng.segment(img, seeds)
+    for lvl in (0, 1, 37, 128, 200, 254):
+        got = eng.level_snapshot(labels, lvl).cpu().numpy().view(np.uint32)
+        assert (got == levels[lvl]).all(), lvl
+    assert (eng.level_snapshot(labels, 254, out=labels).cpu().numpy().view(np.uint32) == levels[254]).all()      # in place
