@@ -232,6 +232,13 @@ int ws_segment_batch_device(ws_ctx *ctx, const uint8_t *d_cube, size_t n_slices,
 int ws_merge_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                     const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
                     uint32_t *d_labels);
+/* Watershed::transform_to_list with everything in HBM: the image, the u32 seed pairs and the lake RECORDS (d_lakes: cap
+ * records in the caller's device buffer; at 1024^2 they are 155 MB that the host form spends most of its time copying).
+ * Only the per-level offsets (max_water_level + 2) and uncoloured counts (max_water_level + 1) go to the host arrays.
+ * Same record layout, order and WS_ERR_CAPACITY protocol as ws_transform_to_list. */
+int ws_transform_to_list_device(ws_ctx *ctx, int merging, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                                const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *d_lakes,
+                                size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured);
 /* Arrival stamps of the last ws_segment_device / ws_merge_device call on this context:
  * (level << 24 | ring), 0 for seeds, 0xFF000000 for never coloured.  Device pointer owned
  * by the context, valid until the next call; shape as the label plane. */

@@ -87,6 +87,8 @@ SIGNATURES = {
     "ws_merge_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
     "ws_transform_to_list": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz,
                                             szp, vp, vp]),
+    "ws_transform_to_list_device": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz,
+                                                   szp, vp, vp]),
     "ws_merge_transform_stub": (ctypes.c_int, [sz, sz, vp]),
     "ws_find_local_minima_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
     "ws_segment_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),

@@ -85,10 +85,11 @@ struct ws_ctx {
     bool merging = false, want_list = false;
     uint32_t levels = 0;
     size_t n_colours = 0, n = 0, cap = 0;
+    const void *records = nullptr;      // the buffer the lake records go to (the context's, or a caller's device buffer)
     uint64_t generation = 0;
     bool operator==(const ListKey &o) const {
       return generation == o.generation && generation != 0 && merging == o.merging && want_list == o.want_list && levels == o.levels &&
-             n_colours == o.n_colours && n == o.n && cap == o.cap;
+             n_colours == o.n_colours && n == o.n && cap == o.cap && records == o.records;
     }
   };
   ListKey list_graph_key, list_seen_key;
@@ -1295,9 +1296,16 @@ int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_siz
   return WS_OK;
 }
 
+// dev (nullable): the device-resident form (ws_transform_to_list_device) -- image and u32 seed pairs are already in HBM and
+// the lake records stay there, in the caller's buffer; only the per-level offsets and uncoloured counts go to the host
+struct DeviceLists {
+  const uint8_t *d_img;
+  const uint32_t *d_seeds_rc;
+  ws_lake *d_lakes;
+};
 int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels,
-               ws_lake *lakes, size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+               ws_lake *lakes, size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured, const DeviceLists *dev = nullptr) {
   if (!c) return WS_ERR_BAD_ARG;
   size_t ph, pw;
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
@@ -1309,9 +1317,15 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   size_t d_stride;
   const uint32_t *d_seeds;
   if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
+  if (!dev && (rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
   stats_begin(c);
-  if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
+  if (dev) {
+    if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
+    d_img = dev->d_img;
+    d_stride = stride;
+    if (opt->edge_correction && h * w == 0 && (rc = empty_image_block(c, &d_img, &d_stride))) return rc;
+    if ((rc = shifted_seeds(c, dev->d_seeds_rc, n_seeds, opt, &d_seeds))) return rc;
+  } else if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
   uint32_t *seg = (uint32_t *)c->labels.p;
   uint64_t *d_out64 = (uint64_t *)c->out64.p;
   // the flood itself is the segmenting one (same coloured set, same arrival stamps: lib.rs:1394-1438 == 1704-1748)
@@ -1319,7 +1333,8 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   const uint32_t *keys = (const uint32_t *)c->keys.p;
   // every buffer first, so that nothing moves once launches (or captured graphs) hold its address
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
-  if (want_list && (rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
+  if (want_list && !dev && (rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
+  uint64_t *d_records = dev ? (uint64_t *)dev->d_lakes : (uint64_t *)c->lakes.p;      // (colour, area) pairs
   if ((rc = build_buckets(c, keys, seg, (int)ph, (int)pw))) return rc;
   uint32_t *parent = (uint32_t *)c->uf_parent.p;
   u64c *mf = (u64c *)c->mflags.p;
@@ -1332,11 +1347,11 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   // merging lists without a hook: level l's records are written by the launch that joins level l + 1's edges
   FusedEmit fe;
   fe.on = merging && want_list && !cb;
-  fe.n_colours = n_seeds + 1; fe.cap = cap; fe.lakes = (uint64_t *)c->lakes.p;
+  fe.n_colours = n_seeds + 1; fe.cap = cap; fe.lakes = d_records;
   if (fe.on) HIP_TRY(c, hipMemsetAsync(c->uf_death.p, 0xFF, (n_seeds + 1) * sizeof(uint32_t), c->stream));      // every colour a root
   auto per_level = [&](uint32_t l) -> int {
     if (want_list && !fe.on)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
-      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_COUNT, l));
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, d_records, cap, mf + MF_LAKE_COUNT, l));
     if (cb) {
       if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
       else HIP_TRY(c, snapshot_level(c->stream, keys, seg, d_out64, n, l));
@@ -1353,6 +1368,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   ws_ctx::ListKey key;
   // (the fused-record mode follows from merging, want_list and cb == null)
   key.merging = merging; key.want_list = want_list; key.levels = levels; key.n_colours = n_seeds + 1; key.n = n; key.cap = cap;
+  key.records = d_records;
   key.generation = c->buffer_generation;
   const bool graph_able = !cb && c->stream != nullptr && !c->graph_unusable && !c->profiling && n != 0;
   bool use_graphs = graph_able && key == c->list_seen_key;
@@ -1394,7 +1410,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   }
   const uint32_t n_groups = (levels + LIST_GROUP - 1) / LIST_GROUP;
   if (fe.on) {      // the last level's records; and a marker behind them: in this mode a group's last level is complete one launch later
-    HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, (uint64_t *)c->lakes.p, cap, mf + MF_LAKE_COUNT, levels - 1,
+    HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, d_records, cap, mf + MF_LAKE_COUNT, levels - 1,
                           (const uint32_t *)c->uf_death.p));
     HIP_TRY(c, hipEventRecord(c->kern_ev[n_groups], c->stream));
   }
@@ -1415,7 +1431,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
       HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
       for (uint32_t l = g0; l < g1; ++l) offsets[l + 1] += offsets[l];      // counts -> offsets
       const size_t end = std::min<size_t>(offsets[g1], cap);
-      if (end > copied) {
+      if (!dev && end > copied) {
         HIP_TRY(c, hipMemcpyAsync(lakes + copied, (const ws_lake *)c->lakes.p + copied, (end - copied) * sizeof(ws_lake), hipMemcpyDeviceToHost, c->copy_stream));
         copied = end;
       }
@@ -1561,6 +1577,16 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
 int ws_merge_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                        size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
   return merge_host(c, true, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels, nullptr, 0, nullptr, nullptr, nullptr);
+}
+
+int ws_transform_to_list_device(ws_ctx *c, int merging, const uint8_t *d_img, size_t h, size_t w, size_t stride,
+                                const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *d_lakes, size_t cap,
+                                size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+  if (!n_lakes || !offsets || !uncoloured || (!d_lakes && cap) || (!d_img && h * w) || (!d_seeds_rc && n_seeds))
+    return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  const DeviceLists dev{d_img, d_seeds_rc, d_lakes};
+  return merge_host(c, merging != 0, nullptr, h, w, stride, nullptr, n_seeds, opt, nullptr, nullptr, nullptr, nullptr, cap, n_lakes, offsets,
+                    uncoloured, &dev);
 }
 
 int ws_transform_to_list(ws_ctx *c, int merging, const uint8_t *img, size_t h, size_t w, size_t stride,

@@ -98,6 +98,32 @@ class DeviceEngine:
         self.ctx.check(_ffi.lib().ws_copy_last_arrival_device(self.ctx.handle, out.data_ptr(), out.numel()))
         return out
 
+    def transform_to_list(self, img, seeds, merging=True, max_level=254, edge=False, lakes=None):
+        """transform_to_list with the records left in HBM: returns (lakes (n, 2) int64 tensor of (colour, area) on the device,
+        offsets numpy (levels + 1), uncoloured numpy (levels)).  `lakes`: a reusable (cap, 2) int64 device buffer."""
+        import numpy as np
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        h, w = img.shape
+        ns = seeds.shape[0] if seeds.dim() == 2 else 0
+        levels = max_level + 1
+        opt = self.options(max_level, edge)
+        offsets = np.zeros(levels + 1, dtype=np.uint64)
+        unc = np.zeros(levels, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        cap = int(lakes.shape[0]) if lakes is not None else max(ns, 1) * levels // 2 + 1024
+        while True:
+            if lakes is None or lakes.shape[0] < cap:
+                lakes = torch.empty((cap, 2), dtype=torch.int64, device=self.device)
+            rc = _ffi.lib().ws_transform_to_list_device(self.ctx.handle, int(merging), img.data_ptr(), h, w, w,
+                                                        seeds.data_ptr() if ns else None, ns, ctypes.byref(opt), lakes.data_ptr(), cap,
+                                                        ctypes.byref(n), offsets.ctypes.data, unc.ctypes.data)
+            if rc == _ffi.WS_ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            self.ctx.check(rc)
+            break
+        return lakes[: n.value], offsets, unc
+
     def level_snapshot(self, labels, water_level, out=None):
         """The segmenting label plane after `water_level` (transform_history's entry for that level), on the device."""
         if out is None:

@@ -286,3 +286,31 @@ def test_to_list_call_sequences_on_one_context_replay_the_right_graphs(pkg):
             assert (ws.transform_final(img, seeds) == final).all(), (shape, maxlvl, rep)
             seg = pkg.TransformBuilder.new().set_max_water_lvl(maxlvl).build_segmenting().transform_to_list_sparse(img, seeds)
             assert sum(int(a.sum()) for _, _, _, a in seg[-1:]) + seg[-1][1] == img.size
+
+
+def test_transform_to_list_device_resident(pkg):
+    # ws_transform_to_list_device: image, seeds and lake records stay in HBM; only offsets and uncoloured counts come back
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    for shape, seed, maxlvl, merging, edge in (((96, 132), 4, 254, True, False), ((70, 64), 5, 90, True, True), ((128, 100), 6, 254, False, False)):
+        himg = cases.field(*shape, seed)
+        hseeds = ol.find_local_minima(himg)
+        want = []
+        if merging:
+            ol.merge_arrival(himg, hseeds, max_level=maxlvl, edge=edge, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(c)))
+        else:
+            ol.segment(himg, hseeds, max_level=maxlvl, edge=edge, hook=lambda l, m, i, c: want.append(ol.find_lake_sizes(c)))
+        img = torch.from_numpy(himg).to(eng.device)
+        seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(eng.device).contiguous()
+        buf = None
+        for rep in range(3):
+            lakes, offsets, unc = eng.transform_to_list(img, seeds, merging=merging, max_level=maxlvl, edge=edge, lakes=buf)
+            buf = lakes if rep == 0 else buf
+            rec = lakes.cpu().numpy()
+            assert len(offsets) == maxlvl + 2 and int(offsets[-1]) == len(rec)
+            for lvl, w in enumerate(want):
+                r = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+                nz = np.nonzero(w[1:])[0] + 1
+                assert unc[lvl] == w[0] and (np.sort(r[:, 0]) == nz).all() and (r[np.argsort(r[:, 0]), 1] == w[nz]).all(), (shape, lvl, rep)
