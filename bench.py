@@ -339,8 +339,13 @@ def run(args):
             k_avg_ms = k_ms / max(k_launches, 1)
             k_bytes_per_launch = k_bytes / max(k_launches, 1)
             achieved = k_bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+            # the same kernel against the bytes its PHASE cannot avoid (every pixel's image byte, seed bit and stamp once):
+            # what is left of `frac` when the re-runs of tiles are not counted as useful bytes
+            k_min_bytes = args.steps * npx_rank * (1 + 0.125 + 4) if args.engine == "fused" else k_bytes
+            k_min_GBps = k_min_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             roof.update({
                 "kernel": kname, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel_minimum_bytes_per_step": int(k_min_bytes / args.steps), "frac_kernel_minimum": round(k_min_GBps / HBM_PEAK_GBS, 5),
                 "avg_launch_ms": round(k_avg_ms, 5), "launches_per_step": round(k_launches / args.steps, 2),
                 "timing": "HIP events around every launch, in a second leg of the same K steps (events off in the timed leg)",
                 "tiles_run_per_step": round(agg["tiles_run_relax"] / args.steps, 1),
