@@ -124,18 +124,17 @@ constexpr uint32_t ST_BORDER = 0x40000000u;      // a border pixel of the tile i
 constexpr uint32_t ST_SELF = 0x80000000u;        // (word 0) the tile stopped at its round cap: it goes on itself
 constexpr uint32_t ST_PASS = 0x3FFFFFFFu;
 
-template <int NW>
+template <int TW, int TH>
 __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
                                                          int otherY, int shifted, uint32_t pass,
                                                          const uint32_t *__restrict__ stamps_prev, int read_same = 0) {
-  constexpr int TH = NW * RX_P;
   const int lane = threadIdx.x & 63;
-  const int ox = shifted ? RX_TW / 2 : 0, oy = shifted ? TH / 2 : 0;
+  const int ox = shifted ? TW / 2 : 0, oy = shifted ? TH / 2 : 0;
   const int t = first + lane * stride;
   const bool mine = lane < chunk && t < tilesX * tilesY;
   const int tx = mine ? t % tilesX : 0, ty = mine ? t / tilesX : 0;
   // a shifted grid can have a last row/column outside the plane
-  bool run = mine && tx * RX_TW - ox < W && ty * TH - oy < H;
+  bool run = mine && tx * TW - ox < W && ty * TH - oy < H;
   if (read_same) {
     // Same-grid passes (the long-range regime): the previous pass ran on THIS grid.  A tile runs when it stopped at its
     // round cap itself, or when a 4-neighbour changed a border pixel on the side facing it -- the two quadrants of the
@@ -187,17 +186,17 @@ __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, 
 // pixel, ring carries included -- by a 6-step inclusive scan over the lanes of the wave: each lane
 // reduces its 4 pixels to one (lo, hi, 4) triple, the scan composes triples, and every lane then knows
 // the value that enters it from its neighbour.  Used only from pass RX_SCAN_FROM_PASS on (the bench field
-// has converged by then; the scan costs registers, so the early passes run a variant without it) and
-// only for tiles that are still moving after RX_SCAN_AFTER rounds.
-// (r2: scans from the first round on and at most two rounds per tile run in those passes -- 8192^2 smooth maps, correlation
-// length 16 / 64 / 256 px: 16.4 -> 13.1, 29.2 -> 22.2, 12.5 -> 10.7 ms; same passes, shorter ones: gpurun_out/r2e)
-constexpr uint32_t RX_SCAN_AFTER = 0;
+// has converged by then; the scan costs registers, so the early passes run a variant without it).
+// (r2: scans from the first round on and a cap on the rounds per tile run in those passes -- 8192^2 smooth maps, correlation
+// length 16 / 64 / 256 px: 16.4 -> 13.1, 29.2 -> 22.2, 12.5 -> 10.7 ms with a cap of two (gpurun_out/r2e); three since the
+// rounds of those passes are scans only and the scans DPP shifts: 8.4 -> 7.2, 8.6 -> 8.3, 4.1 -> 4.0 ms, gpurun_out/r2w/dpp.log)
 constexpr uint32_t RX_SCAN_FROM_PASS = 4;
 constexpr uint32_t RX_EARLY_ROUND_CAP = 4;     // rounds per tile run in passes 1 .. RX_SCAN_FROM_PASS - 1 (0: no cap): smooth 8192^2, correlation 16 px: 12.4 -> 10.4 ms
-constexpr uint32_t RX_LATE_ROUND_CAP = 2;      // rounds per tile run from pass RX_SCAN_FROM_PASS on (0: no cap); see relax_pass
+constexpr uint32_t RX_LATE_ROUND_CAP = 3;      // rounds per tile run from pass RX_SCAN_FROM_PASS on (0: no cap); see relax_pass
 
-template <bool TRACK, bool RIGHT>
-__device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b)[RX_P], uint32_t halo_in, int lane, bool &changed) {
+template <bool TRACK, bool RIGHT, int LX>
+__device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b)[RX_P], uint32_t halo_in, int xl, bool &changed) {
+  // LX lanes make a tile row (64, or 32 when a wave holds two half-width bands: xl = lane & 31, and nothing crosses lane 32)
   // pixels in sweep order
   const uint32_t t0 = RIGHT ? t[0] : t[3], t1 = RIGHT ? t[1] : t[2], t2 = RIGHT ? t[2] : t[1], t3 = RIGHT ? t[3] : t[0];
   const uint32_t b0 = RIGHT ? b[0] : b[3], b1 = RIGHT ? b[1] : b[2], b2 = RIGHT ? b[2] : b[1], b3 = RIGHT ? b[3] : b[0];
@@ -209,21 +208,48 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
   // Every lane adds the same RX_P to what passes through it, so in the coordinate W = v + RX_P * (lanes still to go, this
   // one included) a lane is a PURE clamp [lo + bias, hi + bias], and clamps compose by two medians -- no running sum to
   // carry through the scan, no additions inside it (r2: a third fewer instructions per step, two shuffles instead of three)
-  const uint32_t bias = RIGHT ? (uint32_t)(RX_P * (63 - lane)) : (uint32_t)(RX_P * lane);
+  const uint32_t bias = RIGHT ? (uint32_t)(RX_P * (LX - 1 - xl)) : (uint32_t)(RX_P * xl);
   lo += bias;
   hi += bias;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {       // inclusive scan in sweep order: acc_i <- acc_i o acc_(i -/+ o)
-    const uint32_t plo = RIGHT ? __shfl_up(lo, o, 64) : __shfl_down(lo, o, 64);
-    const uint32_t phi = RIGHT ? __shfl_up(hi, o, 64) : __shfl_down(hi, o, 64);
-    const bool has = RIGHT ? lane >= o : lane + o < 64;
+  // Inclusive scan in sweep order, acc_i <- acc_(i -/+ o) then acc_i, WITHOUT LDS round trips (__shfl_up is a ds_bpermute:
+  // ~100 cycles a step, twelve dependent steps per row and direction, in passes that run at 40 % VALU use): inside a row
+  // of 16 lanes four DPP row shifts whose `old` operand is the identity for lanes with nothing before them (0 for the
+  // lower bound: med3(lo, 0, hi) = lo; ~0 for the upper one), then the rows' totals across rows -- DPP row broadcasts
+  // going right, v_readlane of the rows' first lanes going left (GFX9 has no broadcast in that direction).
+  auto combine = [&](uint32_t plo, uint32_t phi) {
     const uint32_t nlo = med3u(lo, plo, hi), nhi = med3u(lo, phi, hi);      // the earlier clamp, then this one
-    lo = has ? nlo : lo;
-    hi = has ? nhi : hi;
+    lo = nlo; hi = nhi;
+  };
+#define WS_DPP(old, v, ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rows, 0xF, false)
+  if (RIGHT) {
+    combine(WS_DPP(0u, lo, 0x111, 0xF), WS_DPP(~0u, hi, 0x111, 0xF));      // row_shr:1
+    combine(WS_DPP(0u, lo, 0x112, 0xF), WS_DPP(~0u, hi, 0x112, 0xF));      // row_shr:2
+    combine(WS_DPP(0u, lo, 0x114, 0xF), WS_DPP(~0u, hi, 0x114, 0xF));      // row_shr:4
+    combine(WS_DPP(0u, lo, 0x118, 0xF), WS_DPP(~0u, hi, 0x118, 0xF));      // row_shr:8
+    combine(WS_DPP(0u, lo, 0x142, 0xA), WS_DPP(~0u, hi, 0x142, 0xA));      // row_bcast:15 into rows 1 and 3
+    if (LX == 64) combine(WS_DPP(0u, lo, 0x143, 0xC), WS_DPP(~0u, hi, 0x143, 0xC));      // row_bcast:31 into rows 2 and 3
+  } else {
+    combine(WS_DPP(0u, lo, 0x101, 0xF), WS_DPP(~0u, hi, 0x101, 0xF));      // row_shl:1
+    combine(WS_DPP(0u, lo, 0x102, 0xF), WS_DPP(~0u, hi, 0x102, 0xF));      // row_shl:2
+    combine(WS_DPP(0u, lo, 0x104, 0xF), WS_DPP(~0u, hi, 0x104, 0xF));      // row_shl:4
+    combine(WS_DPP(0u, lo, 0x108, 0xF), WS_DPP(~0u, hi, 0x108, 0xF));      // row_shl:8
+    {
+      const int lane = (int)(threadIdx.x & 63u);
+      const uint32_t l16 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 16), h16 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 16);
+      const uint32_t l48 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 48), h48 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 48);
+      const bool r0 = lane < 16, r2 = lane >= 32 && lane < 48;      // rows 0 and 2 take the total of the row after them
+      combine(r0 ? l16 : (r2 ? l48 : 0u), r0 ? h16 : (r2 ? h48 : ~0u));
+      if (LX == 64) {
+        const uint32_t l32 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 32), h32 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 32);
+        combine(lane < 32 ? l32 : 0u, lane < 32 ? h32 : ~0u);
+      }
+    }
   }
+#undef WS_DPP
   // the value that leaves this lane when `halo_in` enters the row, handed to the next lane
-  const uint32_t leaves = med3u(lo, halo_in + (uint32_t)(RX_P * 64), hi) - bias;
-  const uint32_t vin = RIGHT ? lane_left(halo_in, leaves) : lane_right(halo_in, leaves);
+  const uint32_t leaves = med3u(lo, halo_in + (uint32_t)(RX_P * LX), hi) - bias;
+  uint32_t vin = RIGHT ? lane_left(halo_in, leaves) : lane_right(halo_in, leaves);
+  if (LX != 64) vin = (RIGHT ? xl == 0 : xl == LX - 1) ? halo_in : vin;      // the first lane of the second half-row
   const uint32_t n0 = med3u(b0, vin + 1u, t0), n1 = med3u(b1, n0 + 1u, t1), n2 = med3u(b2, n1 + 1u, t2), n3 = med3u(b3, n2 + 1u, t3);
   if (TRACK) changed |= (n0 != t0) | (n1 != t1) | (n2 != t2) | (n3 != t3);
   t[RIGHT ? 0 : 3] = n0; t[RIGHT ? 1 : 2] = n1; t[RIGHT ? 2 : 1] = n2; t[RIGHT ? 3 : 0] = n3;
@@ -233,8 +259,8 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
 // band publishes its four rows of each column as one function in LDS, and a band composes the bands
 // above (below) it -- at most NW - 1 of them -- onto the tile's halo row to get the value that enters
 // its own rows.  Exact, like the row scan; two barriers.
-template <int NW, bool DOWN>
-__device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_row, int band, int lane) {      // fn: [NW][2][RX_TW]
+template <int NB, int TW, bool SPLIT, bool DOWN>
+__device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_row, int band, int xl) {      // fn: [NB][2][TW]
   u32x4_t lo4, hi4;
   uint32_t lo[RX_P], hi[RX_P];
 #pragma unroll
@@ -250,16 +276,29 @@ __device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t
   }
   lo4 = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
   hi4 = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
-  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 0) * RX_TW + lane * RX_P]) = lo4;
-  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 1) * RX_TW + lane * RX_P]) = hi4;
+  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 0) * TW + xl * RX_P]) = lo4;
+  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 1) * TW + xl * RX_P]) = hi4;
   __syncthreads();
-  const u32x4_t h4 = *reinterpret_cast<const u32x4_t *>(&halo_row[lane * RX_P]);
+  const u32x4_t h4 = *reinterpret_cast<const u32x4_t *>(&halo_row[xl * RX_P]);
   uint32_t v[RX_P] = {h4.x, h4.y, h4.z, h4.w};
-  for (int k = DOWN ? 0 : NW - 1; DOWN ? k < band : k > band; k += DOWN ? 1 : -1) {      // wave uniform
-    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * RX_TW + lane * RX_P]);
-    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * RX_TW + lane * RX_P]);
+  // SPLIT: a wave holds the bands 2w (lanes 0..31) and 2w + 1: the loop runs over the bands that BOTH have before them,
+  // and the one band that only one half has before it takes a predicated step
+  const int wave_band = SPLIT ? band & ~1 : band;                       // wave uniform
+  const int last_common = DOWN ? wave_band : (SPLIT ? wave_band + 1 : band);
+  for (int k = DOWN ? 0 : NB - 1; DOWN ? k < last_common : k > last_common; k += DOWN ? 1 : -1) {      // wave uniform
+    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * TW + xl * RX_P]);
+    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * TW + xl * RX_P]);
     v[0] = med3u(l4.x, v[0] + RX_P, g4.x); v[1] = med3u(l4.y, v[1] + RX_P, g4.y);
     v[2] = med3u(l4.z, v[2] + RX_P, g4.z); v[3] = med3u(l4.w, v[3] + RX_P, g4.w);
+  }
+  if (SPLIT) {
+    const int k = DOWN ? wave_band : wave_band + 1;                     // before band 2w + 1 going down, before band 2w going up
+    const bool mine = DOWN ? band != wave_band : band == wave_band;
+    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * TW + xl * RX_P]);
+    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * TW + xl * RX_P]);
+    const uint32_t w0 = med3u(l4.x, v[0] + RX_P, g4.x), w1 = med3u(l4.y, v[1] + RX_P, g4.y);
+    const uint32_t w2 = med3u(l4.z, v[2] + RX_P, g4.z), w3 = med3u(l4.w, v[3] + RX_P, g4.w);
+    v[0] = mine ? w0 : v[0]; v[1] = mine ? w1 : v[1]; v[2] = mine ? w2 : v[2]; v[3] = mine ? w3 : v[3];
   }
 #pragma unroll
   for (int c = 0; c < RX_P; ++c) {
@@ -274,7 +313,7 @@ __device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t
   __syncthreads();          // the functions are rebuilt by the next call
 }
 
-template <int NW, bool CHUNKED, bool SCAN, bool LITE>
+template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
 const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
@@ -282,16 +321,22 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       const uint32_t *__restrict__ stamps_prev, uint32_t *stamps_cur,
                                                       PassFlags pf, uint32_t max_iters,
                                                       const uint32_t *__restrict__ seed_labels, int seed_bits, int SH, int check_carry,
-                                                      int pad, uint32_t scan_after, uint32_t *tile_list, int use_list, int read_same,
+                                                      int pad, uint32_t *tile_list, int use_list, int read_same,
                                                       int write_same, uint32_t list_cap, int append_next) {
   // SH: rows per slice.  A batch of independent slices is one plane of H = S * SH rows in which the first and last row
   // of every slice are image-border rows (never flooded: walls between the slices); SH == H for a single image.
-  constexpr int TH = NW * RX_P;
+  // SPLIT (the same-grid passes of a long-range flood): a wave is TWO bands of half the width -- lanes 0..31 hold four rows
+  // of 128 columns, lanes 32..63 the four rows below them -- so the tile is 128 x 64 instead of 256 x 32.  On a smooth map
+  // the number of passes is set by how far a pass carries a flood vertically, and a pass costs its tile runs whatever
+  // their shape: tools/sim_tile_schedule.c has a quarter to a third fewer of both for the squarer tile.
+  constexpr int LX = SPLIT ? 32 : 64;             // lanes across a tile row
+  constexpr int NB = SPLIT ? 2 * NW : NW;         // bands of RX_P rows
+  constexpr int TW = LX * RX_P, TH = NB * RX_P;
   // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
-  __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NW + 2][RX_TW];
+  __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NB + 2][TW];
   // the tile border as loaded (top row, bottom row, left column, right column): compared with the
   // final values to tell which tile edges changed; parked in LDS to keep the VGPR count at 80
-  __shared__ __attribute__((aligned(16))) uint32_t sInitRow[2][RX_TW];
+  __shared__ __attribute__((aligned(16))) uint32_t sInitRow[2][TW];
   __shared__ uint32_t sInitCol[2][TH];
   __shared__ uint32_t s_edges;
   // "some lane changed in iteration k" lives in slot k % 3: written before barrier k, read after it,
@@ -300,7 +345,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   __shared__ uint32_t s_flag[3];
   __shared__ uint64_t s_sum[64 * NW];        // per-lane patch checksum taken at load time (parked: VGPRs are at the cap)
   // long-range columns (SCAN): every band's four rows of a column as one clamped increment (lo, hi)
-  __shared__ __attribute__((aligned(16))) uint32_t sFn[SCAN ? NW : 1][2][SCAN ? RX_TW : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t sFn[SCAN ? NB : 1][2][SCAN ? TW : 4];
 
 
   // the first wave of workgroup 0 clears the next pass's convergence slot
@@ -324,11 +369,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     n_entries = tile_list[pass & 3u];
     if (entry >= n_entries) return;
   } else if (CHUNKED) {
-    todo = relax_todo<NW>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
+    todo = relax_todo<TW, TH>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
     if (todo == 0) return;
   } else {
     const int tx = first % tilesX, ty = first / tilesX;
-    if (tx * RX_TW - (shifted ? RX_TW / 2 : 0) >= W || ty * TH - (shifted ? TH / 2 : 0) >= H) return;
+    if (tx * TW - (shifted ? TW / 2 : 0) >= W || ty * TH - (shifted ? TH / 2 : 0) >= H) return;
     if (pass != 0) {       // the same test as relax_todo, on scalars (workgroup uniform)
       bool run = false;
 #pragma unroll
@@ -348,13 +393,15 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // per-lane addresses pushed the chunked variant over the 80-VGPR cap and into scratch
   int tid = threadIdx.x;
   if (CHUNKED) asm volatile("" : "+v"(tid));
-  const int lane = tid & 63, band = tid >> 6;
+  const int lane = tid & 63;
+  const int xl = SPLIT ? lane & 31 : lane;                                      // column block of the tile row
+  const int band = SPLIT ? (tid >> 6) * 2 + (lane >> 5) : tid >> 6;             // four-row band of the tile
   const int tile = CHUNKED ? (use_list ? (int)tile_list[4 + (pass & 1u) * list_cap + entry] : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
-  const int x0 = tile_x * RX_TW - (shifted ? RX_TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
+  const int x0 = tile_x * TW - (shifted ? TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
   WS_STAMP(0);
-  const int gx0 = x0 + lane * RX_P, gyb = y0 + band * RX_P;
+  const int gx0 = x0 + xl * RX_P, gyb = y0 + band * RX_P;
   if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
 
   // ---- load phase ---------------------------------------------------------------------------
@@ -364,13 +411,13 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // (patches outside the plane read a clamped address and are masked afterwards: with W % 4 == 0 a
   // patch is either wholly inside or wholly outside)
   // (pad: the image is the caller's unpadded one, read through padded_img_index -- byte loads)
-  const bool fast = !pad && W >= RX_P && ((x0 >= 0 && x0 + RX_TW <= W) || (W & 3) == 0) &&
+  const bool fast = !pad && W >= RX_P && ((x0 >= 0 && x0 + TW <= W) || (W & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
   const int gxc0 = min(max(gx0, 0), max(W - RX_P, 0));
-  // tile halo columns: lanes 0..31 fetch the column left of the tile, lanes 32..63 the one right of
-  // it; only lane 0 / lane 63 ever use the value (as the DPP `old` operand)
-  const int xh = min(max(lane < 32 ? x0 - 1 : x0 + RX_TW, 0), W - 1);
-  const bool xh_ok = lane < 32 ? x0 > 0 : x0 + RX_TW < W;
+  // tile halo columns: the left half of a row's lanes fetch the column left of the tile, the right half the one right
+  // of it; only the first / last lane of a row ever use the value (as the DPP `old` operand)
+  const int xh = min(max(xl < LX / 2 ? x0 - 1 : x0 + TW, 0), W - 1);
+  const bool xh_ok = xl < LX / 2 ? x0 > 0 : x0 + TW < W;
   const int gy_halo_raw = band == 0 ? y0 - 1 : y0 + TH;
   const int gy_halo = min(max(gy_halo_raw, 0), H - 1);
   u32x4_t halo_row;
@@ -450,7 +497,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // Workgroup uniform: the tile and its halo ring lie strictly inside the image (and the image is not a stack of
   // slices) -- every pixel is in the plane and interior, none of the masks below can bite.  These kernels are VALU-bound
   // (VALUBusy 76-84 %, profiles/), and the masks were ~8 ops per pixel of a tile run's ~60.
-  const bool inner = SH == H && x0 >= 1 && x0 + RX_TW <= W - 1 && y0 >= 1 && y0 + TH <= H - 1;
+  const bool inner = SH == H && x0 >= 1 && x0 + TW <= W - 1 && y0 >= 1 && y0 + TH <= H - 1;
   if (!inner) {
     // row inside its slice: the four rows of a patch are all above the plane or all from row 0 on
     const int ry0 = (SH == H || gyb < 0) ? gyb : gyb % SH;
@@ -481,20 +528,43 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // wave shift each, whose `old` operand is the register itself -- lane 0 (lane 63) has no neighbour lane and keeps what
   // it holds, the tile's halo column, for the whole tile run.  (Passing the halo as `old` every time cost a v_mov per
   // shift to set the destination up: 16 of the ~80 vector instructions of a sweep.)
+  // (SPLIT: lane 32 is the first lane of the lower band and lane 31 the last of the upper one: the shift hands them a
+  // value from the other band, which a select replaces with their halo column again)
   uint32_t Lh[RX_P], Rh[RX_P];
 #pragma unroll
   for (int r = 0; r < RX_P; ++r) { Lh[r] = halo[r]; Rh[r] = halo[r]; }
-  {
-    if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][lane * RX_P]) = halo_row;
-    if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NW + 1][lane * RX_P]) = halo_row;
-    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
-    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
-  }
-  if (band == 0) *reinterpret_cast<u32x4_t *>(&sInitRow[0][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
-  if (band == NW - 1) *reinterpret_cast<u32x4_t *>(&sInitRow[1][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
-  if (lane == 0 || lane == 63) {
+  // the tile's halo column as every lane of the row sees it: the register of the row's first / last lane
+  auto row_first = [&](uint32_t v) -> uint32_t {
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    if (!SPLIT) return a;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    return lane < 32 ? a : b;
+  };
+  auto row_last = [&](uint32_t v) -> uint32_t {
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    if (!SPLIT) return b;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    return lane < 32 ? a : b;
+  };
+  auto refresh_columns = [&]() {
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] = T[r][lane == 0 ? 0 : 3];
+    for (int r = 0; r < RX_P; ++r) {
+      Lh[r] = lane_left(Lh[r], T[r][3]);
+      Rh[r] = lane_right(Rh[r], T[r][0]);
+      if (SPLIT) { Lh[r] = lane == 32 ? halo[r] : Lh[r]; Rh[r] = lane == 31 ? halo[r] : Rh[r]; }
+    }
+  };
+  {
+    if (band == 0) *reinterpret_cast<u32x4_t *>(&sRow[0][xl * RX_P]) = halo_row;
+    if (band == NB - 1) *reinterpret_cast<u32x4_t *>(&sRow[2 * NB + 1][xl * RX_P]) = halo_row;
+    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+  }
+  if (band == 0) *reinterpret_cast<u32x4_t *>(&sInitRow[0][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+  if (band == NB - 1) *reinterpret_cast<u32x4_t *>(&sInitRow[1][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+  if (xl == 0 || xl == LX - 1) {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) sInitCol[xl == 0 ? 0 : 1][band * RX_P + r] = T[r][xl == 0 ? 0 : 3];
   }
   __syncthreads();
   WS_STAMP(1);
@@ -520,33 +590,31 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     bool untracked = false;
     uint32_t up[RX_P], dn[RX_P];
     {
-      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
-      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
+      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][xl * RX_P]);
+      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][xl * RX_P]);
       up[0] = up4.x; up[1] = up4.y; up[2] = up4.z; up[3] = up4.w;
       dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
     }
+    if (!SCAN) {
+      refresh_columns();
+      sweep_rows<false, true>(T, B, up, dn, Lh, Rh, untracked);       // down
+      refresh_columns();
+      sweep_cols<false, true>(T, B, up, dn, Lh, Rh, untracked);       // right
+      refresh_columns();
+      sweep_rows<false, false>(T, B, up, dn, Lh, Rh, untracked);      // up
+    } else {
+      // The long-range variant: exact scans right, down, left, up instead of the three sweeps (which move a stamp by one
+      // patch; with them as well a round cost a quarter more and the passes were no fewer: gpurun_out/r2w/skipfree.log).
+      // The checked sweep that follows still sees every pixel's four neighbours: the exit test is the same.
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
-    sweep_rows<false, true>(T, B, up, dn, Lh, Rh, untracked);       // down
+      for (int r = 0; r < RX_P; ++r) scan_row<false, true, LX>(T[r], B[r], row_first(Lh[r]), xl, untracked);
+      scan_cols<NB, TW, SPLIT, true>(T, B, &sFn[0][0][0], sRow[0], band, xl);
 #pragma unroll
-    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
-    sweep_cols<false, true>(T, B, up, dn, Lh, Rh, untracked);       // right
-    const bool long_range = SCAN && round > scan_after;           // workgroup uniform
-    if (long_range) {
-#pragma unroll
-      for (int r = 0; r < RX_P; ++r) scan_row<false, true>(T[r], B[r], __shfl(Lh[r], 0, 64), lane, untracked);
-      scan_cols<NW, true>(T, B, &sFn[0][0][0], sRow[0], band, lane);
+      for (int r = 0; r < RX_P; ++r) scan_row<false, false, LX>(T[r], B[r], row_last(Rh[r]), xl, untracked);
+      scan_cols<NB, TW, SPLIT, false>(T, B, &sFn[0][0][0], sRow[2 * NB + 1], band, xl);
     }
-#pragma unroll
-    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
-    sweep_rows<false, false>(T, B, up, dn, Lh, Rh, untracked);      // up
-    if (long_range) {
-#pragma unroll
-      for (int r = 0; r < RX_P; ++r) scan_row<false, false>(T[r], B[r], __shfl(Rh[r], 63, 64), lane, untracked);
-      scan_cols<NW, false>(T, B, &sFn[0][0][0], sRow[2 * NW + 1], band, lane);
-    }
-    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
-    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+    *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+    *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
     __syncthreads();
   };
   // LITE (passes >= 2: few pixels are still wrong, many flagged tiles need no change at all): the checked sweep comes
@@ -558,19 +626,18 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     bool changed = false;
     uint32_t up[RX_P], dn[RX_P];
     {
-      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][lane * RX_P]);
-      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][lane * RX_P]);
+      const u32x4_t up4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band][xl * RX_P]);
+      const u32x4_t dn4 = *reinterpret_cast<const u32x4_t *>(&sRow[2 * band + 3][xl * RX_P]);
       up[0] = up4.x; up[1] = up4.y; up[2] = up4.z; up[3] = up4.w;
       dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
     }
-#pragma unroll
-    for (int r = 0; r < RX_P; ++r) { Lh[r] = lane_left(Lh[r], T[r][3]); Rh[r] = lane_right(Rh[r], T[r][0]); }
+    refresh_columns();
     sweep_cols<true, false>(T, B, up, dn, Lh, Rh, changed);         // left, checked
     const uint32_t slot = (iters - 1) % 3;
     if (__builtin_amdgcn_ballot_w64(changed) != 0) {
       // a neighbour band reads these rows only if another round follows, i.e. only if someone changed
-      *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][lane * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
-      *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][lane * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
+      *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
+      *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
       if (lane == 0) s_flag[slot] = 1;
     }
     __syncthreads();
@@ -621,19 +688,21 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     // (before a same-grid pass the tile marks ITSELF instead: word 0 of its stamps, below)
     if (unfinished && !write_same) e |= 15u;
     // bit q: a BORDER pixel of the tile inside quadrant q = 2*(lower half) + (right half) changed
-    const uint32_t qbit = 1u << ((band >= NW / 2 ? 2 : 0) + (lane >= 32 ? 1 : 0));
+    const uint32_t qbit = 1u << ((band >= NB / 2 ? 2 : 0) + (xl >= LX / 2 ? 1 : 0));
+    // (bits 6 .. 9: the same changes by SIDE -- top row, bottom row, left column, right column -- for the passes that
+    // stay on one grid, where a side matters to exactly one neighbour)
     if (band == 0) {
-      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][lane * RX_P]);
-      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit;
+      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][xl * RX_P]);
+      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit | 64u;
     }
-    if (band == NW - 1) {
-      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][lane * RX_P]);
-      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit;
+    if (band == NB - 1) {
+      const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][xl * RX_P]);
+      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit | 128u;
     }
-    if (lane == 0 || lane == 63) {
+    if (xl == 0 || xl == LX - 1) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r)
-        if (sInitCol[lane == 0 ? 0 : 1][band * RX_P + r] != T[r][lane == 0 ? 0 : 3]) e |= qbit;
+        if (sInitCol[xl == 0 ? 0 : 1][band * RX_P + r] != T[r][xl == 0 ? 0 : 3]) e |= qbit | (xl == 0 ? 256u : 512u);
     }
   }
   if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
@@ -660,15 +729,16 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       if (ed & 47u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
       if (append_next) {
         // The next pass's tile list, written by the tiles that cause its entries (no k_relax_list launch between two
-        // passes: 5 us of every ~45).  The same rule as relax_todo's same-grid test, from the other side: the neighbour
-        // above sees my upper quadrants (0, 1), the one below my lower ones (2, 3), left 0 and 2, right 1 and 3; I go on
-        // myself if I stopped at the round cap.  A word per tile ("queued for pass p") keeps a tile from entering twice:
+        // passes: 5 us of every ~45).  A tighter rule than relax_todo's same-grid test (which only has the quadrant
+        // stamps): a changed top-row pixel matters to the tile above and to nobody else, and so on round the tile -- a tenth
+        // fewer tile runs on smooth maps than "every neighbour that touches the quadrant"; I go on myself if I stopped at
+        // the round cap.  A word per tile ("queued for pass p") keeps a tile from entering twice:
         // five independent exchanges on clamped slots (slot list_cap is a dummy), then ONE ticket for the new entries.
         uint32_t *queued = tile_list + 4 + 2 * (size_t)list_cap;
         uint32_t *next = tile_list + 4 + ((pass + 1) & 1u) * (size_t)list_cap;
         const uint32_t mark = pass + 1;
-        const bool want[5] = {(ed & 32u) != 0u, (ed & 3u) != 0u && tile_y > 0, (ed & 12u) != 0u && tile_y + 1 < tilesY,
-                              (ed & 5u) != 0u && tile_x > 0, (ed & 10u) != 0u && tile_x + 1 < tilesX};
+        const bool want[5] = {(ed & 32u) != 0u, (ed & 64u) != 0u && tile_y > 0, (ed & 128u) != 0u && tile_y + 1 < tilesY,
+                              (ed & 256u) != 0u && tile_x > 0, (ed & 512u) != 0u && tile_x + 1 < tilesX};
         const uint32_t who[5] = {(uint32_t)t, (uint32_t)(t - tilesX), (uint32_t)(t + tilesX), (uint32_t)(t - 1), (uint32_t)(t + 1)};
         uint32_t old[5];
 #pragma unroll
@@ -718,13 +788,14 @@ constexpr uint32_t RX_SAME_GRID_FROM = 7;
 constexpr uint32_t RX_LIST_FROM_PASS = 6;      // the bench field has converged by then (its passes 4 and 5 find nothing to do)
 constexpr unsigned RX_LIST_GRID = 1024;
 
+template <int TW, int TH>
 __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, int tilesY, int otherX, int otherY, int shifted,
                                                     uint32_t pass, const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list,
                                                     int read_same, uint32_t list_cap) {
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);      // this wave's 64 consecutive tiles
   if ((uint32_t)(first + lane) <= list_cap) tile_list[4 + 2 * (size_t)list_cap + first + lane] = 0u;      // queued marks (and the dummy slot)
-  const unsigned long long todo = relax_todo<RX_NW>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
+  const unsigned long long todo = relax_todo<TW, TH>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
   if (todo == 0) return;
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
@@ -733,13 +804,49 @@ __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, in
     tile_list[4 + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
 }
 
+// The first pass on the 128 x 64 grid (RX_SAME_GRID_FROM): its tile list from the edge stamps that the pass before it left
+// on the 256 x 32 grid.  An equation can only be left violated inside a tile that stopped at its round cap, or next to a
+// border pixel that a tile changed: every new tile that touches an old tile with ANY stamp word of that pass (the old
+// tile's rectangle grown by one pixel) runs -- a superset of the tiles relax_todo would pick, and running a tile that has
+// nothing to do changes nothing.
+template <int TW, int TH, int OTW, int OTH>
+__global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int tilesX, int tilesY, int oldX, int oldY, uint32_t pass,
+                                                           const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list, uint32_t list_cap) {
+  const int lane = threadIdx.x & 63;
+  const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);
+  const int t = first + lane;
+  if ((uint32_t)t <= list_cap) tile_list[4 + 2 * (size_t)list_cap + t] = 0u;      // queued marks (and the dummy slot)
+  bool run = false;
+  if (t < tilesX * tilesY) {
+    const int tx = t % tilesX, ty = t / tilesX;
+    const int x_lo = max(tx * TW - 1, 0) / OTW, x_hi = min((tx * TW + TW) / OTW, oldX - 1);
+    const int y_lo = max(ty * TH - 1, 0) / OTH, y_hi = min((ty * TH + TH) / OTH, oldY - 1);
+    for (int oy = y_lo; oy <= y_hi; ++oy)
+      for (int ox = x_lo; ox <= x_hi; ++ox) {
+        const uint4 st = *reinterpret_cast<const uint4 *>(stamps_prev + ((size_t)oy * oldX + ox) * 4);
+        run |= (st.x & ST_PASS) == pass || (st.y & ST_PASS) == pass || (st.z & ST_PASS) == pass || (st.w & ST_PASS) == pass;
+      }
+    run = run && tx * TW < W && ty * TH < H;
+  }
+  const unsigned long long todo = __builtin_amdgcn_ballot_w64(run);
+  if (todo == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
+  base = __shfl(base, 0, 64);
+  if (run) tile_list[4 + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)t;
+}
+
 // words of scratch relax_pass wants for its tile lists
 size_t relax_list_words(int h, int w) { return 4 + 3 * relax_tiles(h, w) + 64; }      // lengths, two entry arrays, queued marks (+ dummy)
 
-// capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column
+// capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column; the 128 x 64 grid of the
+// same-grid passes has its own count
+constexpr int RX_STW = RX_TW / 2, RX_STH = 2 * RX_NW * RX_P;      // tile of the SPLIT kernel: 128 x 64
 size_t relax_tiles(int h, int w) {
   const int th = RX_NW * RX_P;
-  return (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
+  const size_t a = (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
+  const size_t b = (size_t)((w + RX_STW - 1) / RX_STW + 1) * ((h + RX_STH - 1) / RX_STH + 1);
+  return std::max(a, b);
 }
 
 // Row block of a tiled field: the caller has rewritten the plane's halo rows (row 0 and / or row h - 1).  Only tiles that
@@ -756,8 +863,8 @@ __global__ void k_flag_tile_rows(uint32_t *prev, int sx, int bottom_row, uint32_
 hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w, uint32_t pass, int halo_flags) {
   if ((pass & 1u) != 0 || h == 0 || w == 0) return hipErrorInvalidValue;
   const int th = RX_NW * RX_P;
-  const int sx = (w + RX_TW - 1) / RX_TW + 1, sy = (h + th - 1) / th + 1;
-  const size_t cap = (size_t)sx * sy * 4;
+  const int sx = (w + RX_TW - 1) / RX_TW + 1;
+  const size_t cap = relax_tiles(h, w) * 4;
   // An anchored tile row t runs when row t or t + 1 of the shifted grid is flagged.  What has to run is every tile that
   // holds a pixel NEXT to a halo row, i.e. plane rows 1 (tile row 0: shifted row 0) and h - 2 -- which need not share a
   // tile with the halo row h - 1 itself (a block of 32 k + 1 rows: the halo row has a tile row of its own, and running
@@ -790,10 +897,10 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     return v < 3u ? 3u : (v | 1u);                               // odd: the pass before it runs on the anchored grid
   }();
   const int read_same = pass >= same_from ? 1 : 0, write_same = pass + 1 >= same_from ? 1 : 0;
-  const uint32_t list_cap = (uint32_t)((size_t)sx * sy);      // = relax_tiles(h, w): entries per tile list
+  const uint32_t list_cap = (uint32_t)relax_tiles(h, w);      // entries per tile list
   const int shifted = read_same ? 0 : (int)(pass & 1u);
   const int tx = shifted ? sx : ax, ty = shifted ? sy : ay;
-  const size_t cap = (size_t)sx * sy * 4;
+  const size_t cap = relax_tiles(h, w) * 4;
   const uint32_t *prev = stamps + ((pass + 1) & 1) * cap;
   uint32_t *cur = stamps + (pass & 1) * cap;
   const int ox_ = read_same ? ax : (shifted ? ax : sx), oy_ = read_same ? ay : (shifted ? ay : sy);        // the previous pass's grid
@@ -826,10 +933,6 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     return e ? (uint32_t)atoi(e) : RX_EARLY_ROUND_CAP;
   }();
   if (pass >= 1 && pass < scan_from && early_cap != 0 && early_cap < max_iters) max_iters = early_cap;
-  static const uint32_t scan_after = [] {
-    const char *e = tuning_env("WS_RELAX_SCAN_AFTER");    // tuning knob, tools/ only
-    return e ? (uint32_t)atoi(e) : RX_SCAN_AFTER;
-  }();
   static const uint32_t lite_from = [] {
     const char *e = tuning_env("WS_RELAX_LITE_FROM");     // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 2u;
@@ -843,10 +946,10 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
+                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
-                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
+                                                                      prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
@@ -856,7 +959,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     }();
     if (pass < scan_from) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
+                                                              pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
     } else if (tile_list && pass >= list_from && pass >= scan_from + 1) {
       // (two passes earlier a launch has cleared this pass's counter: every kernel variant does, given a list)
       // From the second same-grid pass on the list is there already: the tiles of the pass before appended it.
@@ -864,19 +967,34 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
       const uint32_t first_list_pass = std::max(list_from, scan_from + 1);
       const int append_next = !no_append && pass >= same_from && pass >= first_list_pass ? 1 : 0;
       const bool appended = !no_append && pass >= 1 && pass - 1 >= same_from && pass - 1 >= first_list_pass;
+      // The same-grid passes run on 128 x 64 tiles (k_relax, SPLIT); the first of them builds its list from the stamps the
+      // 256 x 32 grid left behind.
+      static const bool no_split = tuning_env("WS_RELAX_NO_SPLIT") != nullptr;      // A/B knob, tools/ only
+      const bool split = !no_split && pass >= same_from && same_from >= first_list_pass;
+      const int gx = split ? (w + RX_STW - 1) / RX_STW : tx, gy = split ? (h + RX_STH - 1) / RX_STH : ty;
       if (!appended) {
         // (one thread per tile and a few more: the queued marks, dummy slot included, are cleared here)
-        k_relax_list<<<(unsigned)((std::max<size_t>((size_t)tx * ty, list_cap + 1) + 255) / 256), 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev,
-                                                                                                         tile_list, read_same, list_cap);
+        const unsigned blocks = (unsigned)((std::max<size_t>((size_t)gx * gy, list_cap + 1) + 255) / 256);
+        if (split && pass == same_from)
+          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap);
+        else if (split)
+          k_relax_list<RX_STW, RX_STH><<<blocks, 256, 0, s>>>(h, w, gx, gy, gx, gy, 0, pass, prev, tile_list, 1, list_cap);
+        else
+          k_relax_list<RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, tx, ty, ox_, oy_, shifted, pass, prev, tile_list, read_same, list_cap);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
-      k_relax<RX_NW, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(tx * ty)), 64 * RX_NW, 0, s>>>(
-          img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
-          check_carry, pad, scan_after, tile_list, 1, read_same, write_same, list_cap, append_next);
+      if (split)
+        k_relax<RX_NW, true, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(gx * gy)), 64 * RX_NW, 0, s>>>(
+            img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
+            check_carry, pad, tile_list, 1, 1, 1, list_cap, append_next);
+      else
+        k_relax<RX_NW, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(tx * ty)), 64 * RX_NW, 0, s>>>(
+            img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
+            check_carry, pad, tile_list, 1, read_same, write_same, list_cap, append_next);
     } else {
       k_relax<RX_NW, true, true, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
-                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, scan_after, tile_list, 0, read_same, write_same, list_cap, 0);
+                                                             pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
     }
   }
   return hipGetLastError();

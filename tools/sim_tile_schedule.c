@@ -1,0 +1,237 @@
+/* sim_tile_schedule.c -- CPU model of the relaxation's PASS SCHEDULE and ROUND RECIPE on long-range (smooth) maps: how many
+ * passes, tile runs and rounds a tile geometry / a sequence of sweeps and scans needs, before any kernel is written for it.
+ * Not product code, not the oracle: it solves the same fixpoint  key(p) = max(base(p), 1 + min4 key(q))  (ws_common.hpp)
+ * by the engine's own scheme (ws_relax.hip) and counts.
+ *
+ *   - tiles of TW x TH pixels on one grid; a tile runs when a 4-neighbour changed a border pixel facing it in the pass
+ *     before, or when it stopped at its round cap itself; every tile of a pass reads its halo as the pass found it;
+ *   - a tile run = up to CAP rounds; a round = the operations of RECIPE in order, the last one checked (the run ends when
+ *     it changes nothing):
+ *       D R U L   patch sweeps (4 x 4 patches, Gauss-Seidel inside a patch in the sweep's direction, neighbour patches as
+ *                 they were when the sweep started; rows of OTHER bands as they were at the last barrier)
+ *       r l       exact row scans (right / left) over the whole tile width, from the tile's halo column
+ *       d u       exact column scans (down / up) over the whole tile height, from the tile's halo row
+ *       |         barrier: bands publish their boundary rows (the kernel has one before the checked sweep)
+ *     the kernel's round is "DRrdUlu|L".
+ *
+ *   gcc -O2 -o tools/_build/sim_tile_schedule tools/sim_tile_schedule.c
+ *   sim_tile_schedule image.u8 N seeds.u32 n_seeds TW TH CAP RECIPE [slots]
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KEY_INF 0xFF000000u
+#define PS 4
+
+static uint32_t *key, *base, *snap;
+static int N;
+static long g_rounds, g_ops[128];
+static uint32_t g_side_min[5]; /* smallest new key among the changed pixels of the top / bottom / left / right border, and of the tile */
+
+static inline uint32_t med3(uint32_t lo, uint32_t x, uint32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* tile-local copies: cur (live), beg (at sweep start), bar (at the last barrier); all (th + 2) x (tw + 2) with the halo ring */
+static uint32_t *cur, *beg, *bar, *bs;
+static int P; /* pitch */
+
+static int relax_at(int x, int y, const uint32_t *up, const uint32_t *dn, const uint32_t *lf, const uint32_t *rt) {
+  const int i = y * P + x;
+  const uint32_t t = cur[i], b = bs[i];
+  if (b >= t) return 0;
+  uint32_t m = up[i - P];
+  if (dn[i + P] < m) m = dn[i + P];
+  if (lf[i - 1] < m) m = lf[i - 1];
+  if (rt[i + 1] < m) m = rt[i + 1];
+  const uint32_t n = med3(b, m + 1u, t);
+  if (n == t) return 0;
+  cur[i] = n;
+  return 1;
+}
+
+/* one tile run; returns bit mask: 1 top row changed, 2 bottom, 4 left col, 8 right col, 16 anything, 32 stopped at cap */
+static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe) {
+  P = tw + 2;
+  const size_t cells = (size_t)(th + 2) * P;
+  for (int y = -1; y <= th; ++y)
+    for (int x = -1; x <= tw; ++x) {
+      const int gy = y0 + y, gx = x0 + x, i = (y + 1) * P + x + 1;
+      const int in = gy >= 0 && gy < N && gx >= 0 && gx < N;
+      const int halo = y < 0 || y >= th || x < 0 || x >= tw;
+      cur[i] = in ? (halo ? snap : key)[(size_t)gy * N + gx] : KEY_INF;
+      bs[i] = in && !halo ? base[(size_t)gy * N + gx] : KEY_INF;
+      if (bs[i] > cur[i]) bs[i] = cur[i];
+    }
+  memcpy(bar, cur, cells * 4);
+  int res = 0, round = 0;
+  const int nops = (int)strlen(recipe);
+  for (;;) {
+    int changed_last = 0;
+    for (int k = 0; k < nops; ++k) {
+      const char op = recipe[k];
+      int changed = 0;
+      if (op == '|') { memcpy(bar, cur, cells * 4); continue; }
+      ++g_ops[(int)op];
+      if (op == 'D' || op == 'R' || op == 'U' || op == 'L') {
+        memcpy(beg, cur, cells * 4);
+        for (int py = 0; py < th; py += PS)
+          for (int px = 0; px < tw; px += PS)
+            for (int a = 0; a < PS; ++a)
+              for (int c = 0; c < PS; ++c) {
+                /* D: rows top to bottom, pixels left to right; U: rows bottom to top; R: columns left to right, pixels top
+                 * to bottom; L: columns right to left */
+                const int yy = op == 'D' ? a : (op == 'U' ? PS - 1 - a : c);
+                const int xx = op == 'R' ? a : (op == 'L' ? PS - 1 - a : c);
+                const int x = px + xx + 1, y = py + yy + 1;
+                changed |= relax_at(x, y, yy == 0 ? bar : cur, yy == PS - 1 ? bar : cur, xx == 0 ? beg : cur, xx == PS - 1 ? beg : cur);
+              }
+      } else if (op == 'r' || op == 'l') {
+        for (int y = 1; y <= th; ++y)
+          for (int k2 = 0; k2 < tw; ++k2) {
+            const int x = op == 'r' ? 1 + k2 : tw - k2, i = y * P + x;
+            const uint32_t t = cur[i], b = bs[i];
+            if (b >= t) continue;
+            const uint32_t n = med3(b, cur[op == 'r' ? i - 1 : i + 1] + 1u, t);
+            if (n != t) { cur[i] = n; changed = 1; }
+          }
+      } else if (op == 'V' || op == 'A') {
+        /* scanline pass: rows top to bottom (V) or bottom to top (A); a row first takes what the row before it offers,
+         * then is scanned exactly in both directions: every path that never turns back vertically is settled */
+        for (int k2 = 0; k2 < th; ++k2) {
+          const int y = op == 'V' ? 1 + k2 : th - k2;
+          for (int x = 1; x <= tw; ++x) {
+            const int i = y * P + x;
+            const uint32_t t = cur[i], b = bs[i];
+            if (b >= t) continue;
+            const uint32_t n = med3(b, cur[op == 'V' ? i - P : i + P] + 1u, t);
+            if (n != t) { cur[i] = n; changed = 1; }
+          }
+          for (int dirx = 0; dirx < 2; ++dirx)
+            for (int k3 = 0; k3 < tw; ++k3) {
+              const int x = dirx == 0 ? 1 + k3 : tw - k3, i = y * P + x;
+              const uint32_t t = cur[i], b = bs[i];
+              if (b >= t) continue;
+              const uint32_t n = med3(b, cur[dirx == 0 ? i - 1 : i + 1] + 1u, t);
+              if (n != t) { cur[i] = n; changed = 1; }
+            }
+        }
+      } else if (op == 'd' || op == 'u') {
+        for (int x = 1; x <= tw; ++x)
+          for (int k2 = 0; k2 < th; ++k2) {
+            const int y = op == 'd' ? 1 + k2 : th - k2, i = y * P + x;
+            const uint32_t t = cur[i], b = bs[i];
+            if (b >= t) continue;
+            const uint32_t n = med3(b, cur[op == 'd' ? i - P : i + P] + 1u, t);
+            if (n != t) { cur[i] = n; changed = 1; }
+          }
+      }
+      changed_last = changed;
+    }
+    ++round;
+    ++g_rounds;
+    if (!changed_last) break;
+    if (cap && round >= cap) { res |= 32; break; }
+  }
+  for (int k = 0; k < 5; ++k) g_side_min[k] = 0xFFFFFFFFu;
+  for (int y = 0; y < th && y0 + y < N; ++y)
+    for (int x = 0; x < tw && x0 + x < N; ++x) {
+      const size_t p = (size_t)(y0 + y) * N + x0 + x;
+      const uint32_t n = cur[(y + 1) * P + x + 1];
+      if (n != key[p]) {
+        key[p] = n;
+        res |= 16;
+        if (n < g_side_min[4]) g_side_min[4] = n;
+        if (y == 0) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
+        if (y == th - 1 || y0 + y == N - 1) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
+        if (x == 0) { res |= 4; if (n < g_side_min[2]) g_side_min[2] = n; }
+        if (x == tw - 1 || x0 + x == N - 1) { res |= 8; if (n < g_side_min[3]) g_side_min[3] = n; }
+      }
+    }
+  return res;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 9) { fprintf(stderr, "usage: image N seeds n_seeds TW TH CAP RECIPE [slots]\n"); return 2; }
+  N = atoi(argv[2]);
+  const size_t n = (size_t)N * N;
+  uint8_t *img = malloc(n);
+  FILE *f = fopen(argv[1], "rb");
+  if (!f || fread(img, 1, n, f) != n) { fprintf(stderr, "image\n"); return 1; }
+  fclose(f);
+  const size_t ns = (size_t)atol(argv[4]);
+  uint32_t *seeds = malloc(ns * 4 + 4);
+  f = fopen(argv[3], "rb");
+  if (!f || fread(seeds, 4, ns, f) != ns) { fprintf(stderr, "seeds\n"); return 1; }
+  fclose(f);
+  const int tw = atoi(argv[5]), th = atoi(argv[6]), cap = atoi(argv[7]);
+  const char *recipe = argv[8];
+  const int slots = argc > 9 ? atoi(argv[9]) : 512;
+  key = malloc(n * 4);
+  base = malloc(n * 4);
+  snap = malloc(n * 4);
+  const size_t cells = (size_t)(th + 2) * (tw + 2);
+  cur = malloc(cells * 4); beg = malloc(cells * 4); bar = malloc(cells * 4); bs = malloc(cells * 4);
+  for (size_t p = 0; p < n; ++p) {
+    const int y = (int)(p / N), x = (int)(p % N);
+    const int interior = y >= 1 && y < N - 1 && x >= 1 && x < N - 1;
+    key[p] = KEY_INF;
+    base[p] = interior && img[p] <= 254 ? ((uint32_t)img[p] << 24) | 1u : KEY_INF;
+  }
+  for (size_t i = 0; i < ns; ++i) { key[seeds[i]] = 0; base[seeds[i]] = 0; }
+  const int tx = (N + tw - 1) / tw, ty = (N + th - 1) / th;
+  /* pending[t]: smallest key that is waiting to enter tile t (0xFFFFFFFF: nothing pending).  SIM_DELTA (in ring units; L<n>
+   * = n levels): a pass only runs the tiles whose pending key is within delta of the smallest pending key -- tiles further
+   * up the flood order wait until what reaches them is (more nearly) final. */
+  uint32_t *pending = malloc((size_t)tx * ty * 4), *pnext = malloc((size_t)tx * ty * 4);
+  for (size_t t = 0; t < (size_t)tx * ty; ++t) pending[t] = 0;
+  uint64_t delta = 0;
+  if (getenv("SIM_DELTA")) { const char *e = getenv("SIM_DELTA"); delta = e[0] == 'L' ? (uint64_t)atol(e + 1) << 24 : (uint64_t)atol(e); }
+  /* SIM_ADAPT=lo,hi: delta doubles after a pass that ran fewer than lo tiles while others waited, halves after one that ran more than hi */
+  long adapt_lo = 0, adapt_hi = 0;
+  if (getenv("SIM_ADAPT")) sscanf(getenv("SIM_ADAPT"), "%ld,%ld", &adapt_lo, &adapt_hi);
+  long passes = 0, runs = 0, waves = 0;
+  const int verbose = getenv("SIM_VERBOSE") != NULL;
+  for (;;) {
+    long ran = 0, waiting = 0;
+    const long r0 = g_rounds;
+    uint32_t lowest = 0xFFFFFFFFu;
+    for (size_t t = 0; t < (size_t)tx * ty; ++t) if (pending[t] < lowest) lowest = pending[t];
+    if (lowest == 0xFFFFFFFFu) break;
+    const uint64_t limit = delta && passes > 0 ? (uint64_t)lowest + delta : 0xFFFFFFFEull;
+    for (size_t t = 0; t < (size_t)tx * ty; ++t) pnext[t] = pending[t] != 0xFFFFFFFFu && pending[t] <= limit ? 0xFFFFFFFFu : pending[t];
+    memcpy(snap, key, n * 4);
+    for (int j = 0; j < ty; ++j)
+      for (int i = 0; i < tx; ++i) {
+        const size_t t = (size_t)j * tx + i;
+        if (pending[t] != 0xFFFFFFFFu && pending[t] > limit) ++waiting;
+        if (pending[t] == 0xFFFFFFFFu || pending[t] > limit) continue;
+        ++ran;
+        const int r = run_tile(i * tw, j * th, tw, th, cap, recipe);
+#define RAISE(tt, v) do { if ((v) < pnext[tt]) pnext[tt] = (v); } while (0)
+        if (r & 32) RAISE(t, g_side_min[4]);
+        if ((r & 1) && j > 0) RAISE(t - tx, g_side_min[0]);
+        if ((r & 2) && j + 1 < ty) RAISE(t + tx, g_side_min[1]);
+        if ((r & 4) && i > 0) RAISE(t - 1, g_side_min[2]);
+        if ((r & 8) && i + 1 < tx) RAISE(t + 1, g_side_min[3]);
+      }
+    if (verbose) printf("  pass %ld: tiles %ld rounds %ld lowest %08x\n", passes, ran, g_rounds - r0, lowest);
+    if (adapt_hi && passes > 0) {
+      if (ran < adapt_lo && waiting && delta < (1ull << 31)) delta *= 2;
+      else if (ran > adapt_hi && delta > 16) delta /= 2;
+    }
+    ++passes;
+    runs += ran;
+    waves += (ran + slots - 1) / slots;
+    uint32_t *tt = pending; pending = pnext; pnext = tt;
+  }
+  uint64_t sum = 0;
+  for (size_t p = 0; p < n; ++p) sum += key[p] * (uint64_t)(p % 1000003 + 1);
+  /* vector instructions per wave (ws_relax.hip, ISA counts): a patch sweep ~90, the row scans of a wave's 4 rows ~220, a
+   * column scan ~100; per tile run the load / write-back / flag epilogue ~300 */
+  const double cost = 90.0 * (g_ops['D'] + g_ops['R'] + g_ops['U'] + g_ops['L']) + 220.0 * (g_ops['r'] + g_ops['l']) + 100.0 * (g_ops['d'] + g_ops['u']) + 480.0 * (g_ops['V'] + g_ops['A']) + 300.0 * runs;
+  printf("cost %7.1f M  ", cost / 1e6);
+  printf("tile %4d x %4d cap %d %-12s: passes %5ld  tile runs %8ld (%.1f per tile)  rounds %8ld (%.1f per tile)  slot waves %ld  checksum %llx\n", tw, th,
+         cap, recipe, passes, runs, (double)runs / ((double)tx * ty), g_rounds, (double)g_rounds / ((double)tx * ty), waves, (unsigned long long)sum);
+  return 0;
+}
