@@ -51,7 +51,16 @@ __device__ unsigned long long *g_diag = nullptr;
   do {                                                                                          \
     if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = (v);              \
   } while (0)
+// time spent between two points, summed over a tile run (thread 0's view): WS_ACC_T0 / WS_ACC(slot) pairs
+#define WS_ACC_DECL unsigned long long ws_acc_t = 0, ws_acc[3] = {0, 0, 0}
+#define WS_ACC_T0 (ws_acc_t = __builtin_amdgcn_s_memrealtime())
+#define WS_ACC(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ws_acc[k] += n_ - ws_acc_t; ws_acc_t = n_; } while (0)
+#define WS_ACC_STORE do { if (threadIdx.x == 0 && g_diag) { g_diag[(size_t)blockIdx.x * 8 + 5] = ws_acc[0]; g_diag[(size_t)blockIdx.x * 8 + 6] = ws_acc[1]; g_diag[(size_t)blockIdx.x * 8 + 7] = ws_acc[2]; } } while (0)
 #else
+#define WS_ACC_DECL do {} while (0)
+#define WS_ACC_T0 do {} while (0)
+#define WS_ACC(k) do {} while (0)
+#define WS_ACC_STORE do {} while (0)
 #define WS_STAMP(slot) do {} while (0)
 #define WS_STAMP_VALUE(slot, v) do {} while (0)
 #endif
@@ -364,8 +373,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   unsigned long long todo = 1;
   // list mode (late passes of a long-range flood): the tiles to run were compacted by k_relax_list; workgroup b takes
   // entries b, b + gridDim.x, ... -- no workgroup is launched for a tile that has nothing to do, none owns two busy ones
-  uint32_t entry = blockIdx.x, n_entries = 0;
+  uint32_t entry = blockIdx.x, n_entries = 0, first_entry = 0;
   if (CHUNKED && use_list) {
+    // (the workgroup's first entry is asked for together with the list length, not after it: one memory round trip less
+    // at the head of every tile run of a thin pass, which IS such a pass's length)
+    first_entry = tile_list[4 + (pass & 1u) * list_cap + min(entry, list_cap - 1u)];
     n_entries = tile_list[pass & 3u];
     if (entry >= n_entries) return;
   } else if (CHUNKED) {
@@ -396,7 +408,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   const int lane = tid & 63;
   const int xl = SPLIT ? lane & 31 : lane;                                      // column block of the tile row
   const int band = SPLIT ? (tid >> 6) * 2 + (lane >> 5) : tid >> 6;             // four-row band of the tile
-  const int tile = CHUNKED ? (use_list ? (int)tile_list[4 + (pass & 1u) * list_cap + entry] : first + (int)__builtin_ctzll(todo) * stride) : first;
+  const int tile = CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[4 + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = tile_x * TW - (shifted ? TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
@@ -584,6 +596,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     s_sum[tid] = sum_before;
   }
   uint32_t iters = 0;
+  WS_ACC_DECL;
   bool unfinished = max_iters == 0;      // left before the checked sweep came back clean (round cap)
   // the three free sweeps of a round, then the band boundary rows are published
   auto free_sweeps = [&](uint32_t round) {
@@ -606,12 +619,17 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       // The long-range variant: exact scans right, down, left, up instead of the three sweeps (which move a stamp by one
       // patch; with them as well a round cost a quarter more and the passes were no fewer: gpurun_out/r2w/skipfree.log).
       // The checked sweep that follows still sees every pixel's four neighbours: the exit test is the same.
+      WS_ACC_T0;
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, true, LX>(T[r], B[r], row_first(Lh[r]), xl, untracked);
+      WS_ACC(0);
       scan_cols<NB, TW, SPLIT, true>(T, B, &sFn[0][0][0], sRow[0], band, xl);
+      WS_ACC(1);
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, false, LX>(T[r], B[r], row_last(Rh[r]), xl, untracked);
+      WS_ACC(0);
       scan_cols<NB, TW, SPLIT, false>(T, B, &sFn[0][0][0], sRow[2 * NB + 1], band, xl);
+      WS_ACC(1);
     }
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
     *reinterpret_cast<u32x4_t *>(&sRow[2 + 2 * band][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
@@ -631,8 +649,10 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       up[0] = up4.x; up[1] = up4.y; up[2] = up4.z; up[3] = up4.w;
       dn[0] = dn4.x; dn[1] = dn4.y; dn[2] = dn4.z; dn[3] = dn4.w;
     }
+    WS_ACC_T0;
     refresh_columns();
     sweep_cols<true, false>(T, B, up, dn, Lh, Rh, changed);         // left, checked
+    WS_ACC(2);
     const uint32_t slot = (iters - 1) % 3;
     if (__builtin_amdgcn_ballot_w64(changed) != 0) {
       // a neighbour band reads these rows only if another round follows, i.e. only if someone changed
@@ -657,6 +677,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     any_lower = sum_after != s_sum[tid];
   }
   WS_STAMP(2);
+  WS_ACC_STORE;
 #ifdef WS_DIAG_STAMPS
   if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = iters;
 #endif
@@ -733,7 +754,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
         // stamps): a changed top-row pixel matters to the tile above and to nobody else, and so on round the tile -- a tenth
         // fewer tile runs on smooth maps than "every neighbour that touches the quadrant"; I go on myself if I stopped at
         // the round cap.  A word per tile ("queued for pass p") keeps a tile from entering twice:
-        // five independent exchanges on clamped slots (slot list_cap is a dummy), then ONE ticket for the new entries.
+        // five independent exchanges on clamped slots (64 dummy slots from list_cap on, picked by tile), then ONE ticket for the
+        // new entries.
         uint32_t *queued = tile_list + 4 + 2 * (size_t)list_cap;
         uint32_t *next = tile_list + 4 + ((pass + 1) & 1u) * (size_t)list_cap;
         const uint32_t mark = pass + 1;
@@ -742,7 +764,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
         const uint32_t who[5] = {(uint32_t)t, (uint32_t)(t - tilesX), (uint32_t)(t + tilesX), (uint32_t)(t - 1), (uint32_t)(t + 1)};
         uint32_t old[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) old[k] = atomicExch(&queued[want[k] ? who[k] : list_cap], mark);
+        for (int k = 0; k < 5; ++k) old[k] = atomicExch(&queued[want[k] ? who[k] : list_cap + (uint32_t)((t + k) & 63)], mark);
         uint32_t fresh = 0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) fresh += (want[k] && old[k] != mark) ? 1u : 0u;
