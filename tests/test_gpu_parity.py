@@ -552,11 +552,14 @@ def test_segment_batch_stacked_with_an_unsorted_list_does_not_chase_garbage(pkg)
             assert (got[k] == ol.segment_arrival(himgs[k], sorted_lists[k].astype(np.uint64))).all(), k
 
 
-@pytest.mark.parametrize("shape,octaves", [((1000, 1300), 6), ((777, 1001), 6), ((1500, 640), 7), ((2100, 300), 5)])
+@pytest.mark.parametrize("shape,octaves", [((1000, 1300), 6), ((777, 1001), 6), ((1500, 640), 7), ((2100, 300), 5),
+                                           ((193, 1290), 5), ((1290, 193), 5), ((449, 385), 6), ((129, 2050), 5), ((640, 1024), 6)])
 def test_long_range_passes_on_one_grid_odd_shapes(pkg, shape, octaves):
-    # the late passes (compacted tile lists from pass 6, ONE grid from pass 7, round caps) on shapes whose last tile row /
-    # column is partial, on a width that is not a multiple of 4 (scalar loads), and on a tall narrow plane; few seeds, so
-    # that single floods cross the whole plane, and all maxima, so that hundreds of fronts meet
+    # the late passes (compacted tile lists from pass 6, ONE grid of 128 x 64 tiles from pass 7 -- two half-width bands per
+    # wave --, round caps) on shapes whose last tile row / column is partial in either geometry (one pixel past a multiple of
+    # 64 rows / 128 columns, exact multiples, a plane of one tile and a bit), on a width that is not a multiple of 4
+    # (scalar loads), and on a tall narrow plane; few seeds, so that single floods cross the whole plane, and all maxima,
+    # so that hundreds of fronts meet
     img = cases.smooth_field(*shape, 23, octaves=octaves)
     allseeds = ol.find_local_minima(img)
     ws = _seg(pkg, pkg.ENGINE_FUSED)
