@@ -132,6 +132,9 @@ __device__ __forceinline__ void sweep_cols(patch_t &T, const patch_t &B, const u
 constexpr uint32_t ST_BORDER = 0x40000000u;      // a border pixel of the tile inside this quadrant changed
 constexpr uint32_t ST_SELF = 0x80000000u;        // (word 0) the tile stopped at its round cap: it goes on itself
 constexpr uint32_t ST_PASS = 0x3FFFFFFFu;
+constexpr uint32_t RX_CAND = 64;      // candidates a workgroup collects before it hands them in (k_relax, append_flush)
+// tile_list header: [0 .. 3] list lengths and [4 .. 7] entry tickets of pass & 3 (a launch clears the words of pass + 2)
+constexpr uint32_t RL_HDR = 8;
 
 template <int TW, int TH>
 __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
@@ -264,62 +267,68 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
   t[RIGHT ? 0 : 3] = n0; t[RIGHT ? 1 : 2] = n1; t[RIGHT ? 2 : 1] = n2; t[RIGHT ? 3 : 0] = n3;
 }
 
-// The same idea down the columns of a tile: the rows of a column live in NW different waves, so every
-// band publishes its four rows of each column as one function in LDS, and a band composes the bands
-// above (below) it -- at most NW - 1 of them -- onto the tile's halo row to get the value that enters
-// its own rows.  Exact, like the row scan; two barriers.
-template <int NB, int TW, bool SPLIT, bool DOWN>
-__device__ __forceinline__ void scan_cols(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_row, int band, int xl) {      // fn: [NB][2][TW]
-  u32x4_t lo4, hi4;
-  uint32_t lo[RX_P], hi[RX_P];
+// The same idea down AND up the columns of a tile, in one phase: the rows of a column live in NB different bands (waves, or
+// halves of waves), so every band publishes its four rows of each column as two clamped increments in LDS -- entered from
+// above, entered from below -- and then composes the bands above it onto the tile's upper halo row and the bands below it
+// onto the lower one: NB - 1 LDS reads for every band, whichever it is, one barrier.  Then its own rows downwards from
+// what came from above, and upwards from what came from below.  Exact relaxation steps, like the row scan; what enters
+// from the other bands is their state when the phase began.
+// (r2, first form: a scan down and a scan up, each with its own barriers and with 0 .. NB - 1 dependent reads depending
+// on the band -- the last band walked 15 bands while the others waited, twice per round: 4 of the 6.6 us of a tile run's
+// rounds, tools/diag_relax_smooth.hip.  tools/sim_tile_schedule.c, recipes "rdlu|L|" and "rlc|L|": same passes, tile
+// runs and rounds either way.)
+template <int NB, int TW, bool SPLIT>
+__device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_top, const uint32_t *halo_bottom,
+                                               int band, int xl) {      // fn: [2][NB][2][TW]: direction, band, (lo, hi)
+  auto slot = [&](int dir, int k, int which) { return fn + (((size_t)dir * NB + k) * 2 + which) * TW + xl * RX_P; };
+  {
+    uint32_t lo[RX_P], hi[RX_P];
 #pragma unroll
-  for (int c = 0; c < RX_P; ++c) {
-    uint32_t h = T[DOWN ? 0 : 3][c], l = B[DOWN ? 0 : 3][c];
+    for (int dir = 0; dir < 2; ++dir) {      // 0: entered from above, rows 0 .. 3; 1: from below, rows 3 .. 0
 #pragma unroll
-    for (int k = 1; k < RX_P; ++k) {
-      const int r = DOWN ? k : RX_P - 1 - k;
-      h = med3u(B[r][c], h + 1u, T[r][c]);
-      l = med3u(B[r][c], l + 1u, T[r][c]);
+      for (int c = 0; c < RX_P; ++c) {
+        uint32_t h = T[dir ? 3 : 0][c], l = B[dir ? 3 : 0][c];
+#pragma unroll
+        for (int k = 1; k < RX_P; ++k) {
+          const int r = dir ? RX_P - 1 - k : k;
+          h = med3u(B[r][c], h + 1u, T[r][c]);
+          l = med3u(B[r][c], l + 1u, T[r][c]);
+        }
+        lo[c] = l; hi[c] = h;
+      }
+      *reinterpret_cast<u32x4_t *>(slot(dir, band, 0)) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+      *reinterpret_cast<u32x4_t *>(slot(dir, band, 1)) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
     }
-    lo[c] = l; hi[c] = h;
   }
-  lo4 = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
-  hi4 = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
-  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 0) * TW + xl * RX_P]) = lo4;
-  *reinterpret_cast<u32x4_t *>(&fn[(band * 2 + 1) * TW + xl * RX_P]) = hi4;
   __syncthreads();
-  const u32x4_t h4 = *reinterpret_cast<const u32x4_t *>(&halo_row[xl * RX_P]);
-  uint32_t v[RX_P] = {h4.x, h4.y, h4.z, h4.w};
-  // SPLIT: a wave holds the bands 2w (lanes 0..31) and 2w + 1: the loop runs over the bands that BOTH have before them,
-  // and the one band that only one half has before it takes a predicated step
-  const int wave_band = SPLIT ? band & ~1 : band;                       // wave uniform
-  const int last_common = DOWN ? wave_band : (SPLIT ? wave_band + 1 : band);
-  for (int k = DOWN ? 0 : NB - 1; DOWN ? k < last_common : k > last_common; k += DOWN ? 1 : -1) {      // wave uniform
-    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * TW + xl * RX_P]);
-    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * TW + xl * RX_P]);
-    v[0] = med3u(l4.x, v[0] + RX_P, g4.x); v[1] = med3u(l4.y, v[1] + RX_P, g4.y);
-    v[2] = med3u(l4.z, v[2] + RX_P, g4.z); v[3] = med3u(l4.w, v[3] + RX_P, g4.w);
-  }
-  if (SPLIT) {
-    const int k = DOWN ? wave_band : wave_band + 1;                     // before band 2w + 1 going down, before band 2w going up
-    const bool mine = DOWN ? band != wave_band : band == wave_band;
-    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 0) * TW + xl * RX_P]);
-    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(&fn[(k * 2 + 1) * TW + xl * RX_P]);
+  const u32x4_t t4 = *reinterpret_cast<const u32x4_t *>(&halo_top[xl * RX_P]);
+  const u32x4_t b4 = *reinterpret_cast<const u32x4_t *>(&halo_bottom[xl * RX_P]);
+  uint32_t vd[RX_P] = {t4.x, t4.y, t4.z, t4.w}, vu[RX_P] = {b4.x, b4.y, b4.z, b4.w};
+  auto step = [&](uint32_t (&v)[RX_P], int dir, int k, bool mine) {
+    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(slot(dir, k, 0));
+    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(slot(dir, k, 1));
     const uint32_t w0 = med3u(l4.x, v[0] + RX_P, g4.x), w1 = med3u(l4.y, v[1] + RX_P, g4.y);
     const uint32_t w2 = med3u(l4.z, v[2] + RX_P, g4.z), w3 = med3u(l4.w, v[3] + RX_P, g4.w);
     v[0] = mine ? w0 : v[0]; v[1] = mine ? w1 : v[1]; v[2] = mine ? w2 : v[2]; v[3] = mine ? w3 : v[3];
-  }
+  };
+  // SPLIT: a wave holds the bands 2w (lanes 0..31) and 2w + 1: the loops run over the bands that BOTH have before them,
+  // and the one band that only one half has before it takes a predicated step
+  const int lo_band = SPLIT ? band & ~1 : band, hi_band = SPLIT ? band | 1 : band;      // wave uniform
+  for (int k = 0; k < lo_band; ++k) step(vd, 0, k, true);
+  if (SPLIT) step(vd, 0, lo_band, band != lo_band);
+  for (int k = NB - 1; k > hi_band; --k) step(vu, 1, k, true);
+  if (SPLIT) step(vu, 1, hi_band, band != hi_band);
 #pragma unroll
   for (int c = 0; c < RX_P; ++c) {
-    uint32_t n = v[c];
+    uint32_t n = vd[c];
 #pragma unroll
-    for (int k = 0; k < RX_P; ++k) {
-      const int r = DOWN ? k : RX_P - 1 - k;
-      n = med3u(B[r][c], n + 1u, T[r][c]);
-      T[r][c] = n;
-    }
+    for (int r = 0; r < RX_P; ++r) { n = med3u(B[r][c], n + 1u, T[r][c]); T[r][c] = n; }
+    n = vu[c];
+#pragma unroll
+    for (int r = RX_P - 1; r >= 0; --r) { n = med3u(B[r][c], n + 1u, T[r][c]); T[r][c] = n; }
   }
-  __syncthreads();          // the functions are rebuilt by the next call
+  // (no barrier here: two lie between this phase and the next write of the functions -- the end of the round's free part
+  // and the checked sweep's)
 }
 
 template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false>
@@ -348,13 +357,19 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   __shared__ __attribute__((aligned(16))) uint32_t sInitRow[2][TW];
   __shared__ uint32_t sInitCol[2][TH];
   __shared__ uint32_t s_edges;
+  // list mode: the tiles this workgroup's runs want in the next pass's list, handed in together -- a "queued" exchange
+  // and a list ticket are two dependent atomic round trips, 3 of the 4.5 us a tile run's epilogue took with seven of the
+  // eight waves idle (tools/diag_relax_smooth.hip); a workgroup runs ~5 tiles in a heavy pass and now pays them once
+  __shared__ uint32_t s_cand[RX_CAND];
+  __shared__ uint32_t s_ncand;
+  __shared__ uint32_t s_next[2];             // list mode: the entry this workgroup takes after the current one (by run parity)
   // "some lane changed in iteration k" lives in slot k % 3: written before barrier k, read after it,
   // cleared by thread 0 for iteration k + 2 -- one barrier per iteration instead of the three a
   // __syncthreads_or costs
   __shared__ uint32_t s_flag[3];
   __shared__ uint64_t s_sum[64 * NW];        // per-lane patch checksum taken at load time (parked: VGPRs are at the cap)
   // long-range columns (SCAN): every band's four rows of a column as one clamped increment (lo, hi)
-  __shared__ __attribute__((aligned(16))) uint32_t sFn[SCAN ? NB : 1][2][SCAN ? TW : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t sFn[2][SCAN ? NB : 1][2][SCAN ? TW : 4];
 
 
   // the first wave of workgroup 0 clears the next pass's convergence slot
@@ -364,7 +379,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // (tile_list: [0..3] list lengths of pass & 3; [4 ...) entries of the even passes, then of the odd ones, then one
   // "queued for pass" word per tile.  This launch reads the list of `pass`, may append to the list of pass + 1, and clears
   // the length that pass + 2 will count up from.)
-  if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) tile_list[(pass + 2) & 3u] = 0u;
+  if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) { tile_list[(pass + 2) & 3u] = 0u; tile_list[4 + ((pass + 2) & 3u)] = 0u; }
   // (XCD-aware: consecutive workgroups go to different XCDs; see xcd_span_index)
   // A chunk is `chunk` tiles one grid size apart, not neighbours: on a smooth map the tiles that still
   // run line up along a front, and four neighbours in one workgroup ran one after the other.
@@ -373,11 +388,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   unsigned long long todo = 1;
   // list mode (late passes of a long-range flood): the tiles to run were compacted by k_relax_list; workgroup b takes
   // entries b, b + gridDim.x, ... -- no workgroup is launched for a tile that has nothing to do, none owns two busy ones
-  uint32_t entry = blockIdx.x, n_entries = 0, first_entry = 0;
+  uint32_t entry = blockIdx.x, n_entries = 0, first_entry = 0, runs_done = 0;
   if (CHUNKED && use_list) {
     // (the workgroup's first entry is asked for together with the list length, not after it: one memory round trip less
     // at the head of every tile run of a thin pass, which IS such a pass's length)
-    first_entry = tile_list[4 + (pass & 1u) * list_cap + min(entry, list_cap - 1u)];
+    first_entry = tile_list[RL_HDR + (pass & 1u) * list_cap + min(entry, list_cap - 1u)];
     n_entries = tile_list[pass & 3u];
     if (entry >= n_entries) return;
   } else if (CHUNKED) {
@@ -400,6 +415,27 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       if (!run) return;
     }
   }
+  if (threadIdx.x == 0) s_ncand = 0;      // (read again only after the first tile's barriers)
+  // Wave 0, all lanes: one "queued for pass p" exchange per candidate (a tile enters a list once: whoever finds the old
+  // mark adds it), one ticket for the new entries of all of them.
+  auto append_flush = [&]() {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = s_ncand;
+    uint32_t *queued = tile_list + RL_HDR + 2 * (size_t)list_cap;
+    uint32_t *next = tile_list + RL_HDR + ((pass + 1) & 1u) * (size_t)list_cap;
+    const uint32_t mark = pass + 1;
+    const bool mine = (uint32_t)lane < n;
+    const uint32_t cand = mine ? s_cand[lane] : 0u;
+    const bool fresh = mine && atomicExch(&queued[cand], mark) != mark;
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
+    if (fm) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&tile_list[(pass + 1) & 3u], (uint32_t)__popcll(fm));
+      at = __shfl(at, 0, 64);
+      if (fresh) next[at + __popcll(fm & ((1ull << lane) - 1ull))] = cand;
+    }
+    if (lane == 0) s_ncand = 0;
+  };
   for (;;) {
   // re-derived per tile on purpose (the asm hides the value from loop-invariant hoisting): hoisted
   // per-lane addresses pushed the chunked variant over the 80-VGPR cap and into scratch
@@ -408,13 +444,17 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   const int lane = tid & 63;
   const int xl = SPLIT ? lane & 31 : lane;                                      // column block of the tile row
   const int band = SPLIT ? (tid >> 6) * 2 + (lane >> 5) : tid >> 6;             // four-row band of the tile
-  const int tile = CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[4 + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first;
+  const int tile = CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[RL_HDR + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = tile_x * TW - (shifted ? TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
 
   WS_STAMP(0);
   const int gx0 = x0 + xl * RX_P, gyb = y0 + band * RX_P;
   if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+  // List mode: entries are handed out by ticket, not in strides of the grid -- tile runs last 8 to 20 us, and with a fixed
+  // share a pass ended with most workgroups gone and a few still on their third tile.  The ticket for the NEXT entry is
+  // drawn now and read after the run: its round trip hides behind the tile.
+  if (CHUNKED && use_list && tid == 0) s_next[runs_done & 1u] = gridDim.x + atomicAdd(&tile_list[4 + (pass & 3u)], 1u);
 
   // ---- load phase ---------------------------------------------------------------------------
   uint32_t T[RX_P][RX_P], B[RX_P][RX_P], halo[RX_P];
@@ -616,19 +656,16 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       refresh_columns();
       sweep_rows<false, false>(T, B, up, dn, Lh, Rh, untracked);      // up
     } else {
-      // The long-range variant: exact scans right, down, left, up instead of the three sweeps (which move a stamp by one
+      // The long-range variant: exact scans right, left, then down and up in one phase, instead of the three sweeps (which move a stamp by one
       // patch; with them as well a round cost a quarter more and the passes were no fewer: gpurun_out/r2w/skipfree.log).
       // The checked sweep that follows still sees every pixel's four neighbours: the exit test is the same.
       WS_ACC_T0;
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, true, LX>(T[r], B[r], row_first(Lh[r]), xl, untracked);
-      WS_ACC(0);
-      scan_cols<NB, TW, SPLIT, true>(T, B, &sFn[0][0][0], sRow[0], band, xl);
-      WS_ACC(1);
 #pragma unroll
       for (int r = 0; r < RX_P; ++r) scan_row<false, false, LX>(T[r], B[r], row_last(Rh[r]), xl, untracked);
       WS_ACC(0);
-      scan_cols<NB, TW, SPLIT, false>(T, B, &sFn[0][0][0], sRow[2 * NB + 1], band, xl);
+      scan_cols_both<NB, TW, SPLIT>(T, B, &sFn[0][0][0][0], sRow[0], sRow[2 * NB + 1], band, xl);
       WS_ACC(1);
     }
     *reinterpret_cast<u32x4_t *>(&sRow[1 + 2 * band][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
@@ -749,31 +786,19 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       // plain, idempotent stores into striped words: no same-address atomics on the tile path
       if (ed & 47u) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
       if (append_next) {
-        // The next pass's tile list, written by the tiles that cause its entries (no k_relax_list launch between two
+        // The next pass's tile list is written by the tiles that cause its entries (no k_relax_list launch between two
         // passes: 5 us of every ~45).  A tighter rule than relax_todo's same-grid test (which only has the quadrant
         // stamps): a changed top-row pixel matters to the tile above and to nobody else, and so on round the tile -- a tenth
         // fewer tile runs on smooth maps than "every neighbour that touches the quadrant"; I go on myself if I stopped at
-        // the round cap.  A word per tile ("queued for pass p") keeps a tile from entering twice:
-        // five independent exchanges on clamped slots (64 dummy slots from list_cap on, picked by tile), then ONE ticket for the
-        // new entries.
-        uint32_t *queued = tile_list + 4 + 2 * (size_t)list_cap;
-        uint32_t *next = tile_list + 4 + ((pass + 1) & 1u) * (size_t)list_cap;
-        const uint32_t mark = pass + 1;
+        // the round cap.  The candidates only go to LDS here: the workgroup hands them in together (append_flush).
         const bool want[5] = {(ed & 32u) != 0u, (ed & 64u) != 0u && tile_y > 0, (ed & 128u) != 0u && tile_y + 1 < tilesY,
                               (ed & 256u) != 0u && tile_x > 0, (ed & 512u) != 0u && tile_x + 1 < tilesX};
         const uint32_t who[5] = {(uint32_t)t, (uint32_t)(t - tilesX), (uint32_t)(t + tilesX), (uint32_t)(t - 1), (uint32_t)(t + 1)};
-        uint32_t old[5];
+        uint32_t n = s_ncand;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) old[k] = atomicExch(&queued[want[k] ? who[k] : list_cap + (uint32_t)((t + k) & 63)], mark);
-        uint32_t fresh = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) fresh += (want[k] && old[k] != mark) ? 1u : 0u;
-        if (fresh) {
-          uint32_t at = atomicAdd(&tile_list[(pass + 1) & 3u], fresh);
-#pragma unroll
-          for (int k = 0; k < 5; ++k)
-            if (want[k] && old[k] != mark) next[at++] = who[k];
-        }
+        for (int k = 0; k < 5; ++k)
+          if (want[k]) s_cand[n++] = who[k];
+        s_ncand = n;
       }
       pf.any_change[stripe] = 1u;
     }
@@ -786,8 +811,12 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // next tile of the chunk: every wave is past its last read of the shared arrays (barrier above)
   if (!CHUNKED) break;
   if (use_list) {
-    entry += gridDim.x;
-    if (entry >= n_entries) break;
+    entry = s_next[runs_done & 1u];      // (written before this run's first barrier)
+    ++runs_done;
+    const bool last = entry >= n_entries;
+    // wave 0 hands the candidates in: when this was the workgroup's last tile, or when another tile's five might not fit
+    if (append_next && tid < 64 && (last || s_ncand > RX_CAND - 5u)) append_flush();
+    if (last) break;
   } else {
     todo &= todo - 1;
     if (todo == 0) break;
@@ -797,7 +826,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 
 constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
 
-// The tiles that have to run in `pass`, compacted: tile_list[pass & 3] = how many, entries from tile_list[4 + (pass & 1) *
+// The tiles that have to run in `pass`, compacted: tile_list[pass & 3] = how many, entries from tile_list[RL_HDR + (pass & 1) *
 // list_cap] on (any order).  It also clears the tiles' "queued for pass" words, which the passes that append their
 // successors' lists themselves (k_relax, append_next) exchange: every transform that reaches those passes comes through here.
 // Same test as relax_todo; one atomicAdd per wave that found any.  Worth its own launch only when few tiles run: on a
@@ -808,7 +837,7 @@ constexpr int RX_NW = 8;   // 512 threads: tile 256 x 32
 // 64 / 256 px: 436 -> 260 and 516 -> 292 passes, 16.8 -> 12.6 and 11.0 -> 7.0 ms (gpurun_out/r2k, bit-exact)
 constexpr uint32_t RX_SAME_GRID_FROM = 7;
 constexpr uint32_t RX_LIST_FROM_PASS = 6;      // the bench field has converged by then (its passes 4 and 5 find nothing to do)
-constexpr unsigned RX_LIST_GRID = 1024;
+constexpr unsigned RX_LIST_GRID = 512;       // two workgroups of the scan variant per CU: all resident, the tickets share the list out
 
 template <int TW, int TH>
 __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, int tilesY, int otherX, int otherY, int shifted,
@@ -816,14 +845,14 @@ __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, in
                                                     int read_same, uint32_t list_cap) {
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);      // this wave's 64 consecutive tiles
-  if ((uint32_t)(first + lane) <= list_cap) tile_list[4 + 2 * (size_t)list_cap + first + lane] = 0u;      // queued marks (and the dummy slot)
+  if ((uint32_t)(first + lane) <= list_cap) tile_list[RL_HDR + 2 * (size_t)list_cap + first + lane] = 0u;      // queued marks (and the dummy slot)
   const unsigned long long todo = relax_todo<TW, TH>(first, 1, 64, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
   if (todo == 0) return;
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
   base = __shfl(base, 0, 64);
   if ((todo >> lane) & 1ull)
-    tile_list[4 + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
+    tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)(first + lane);
 }
 
 // The first pass on the 128 x 64 grid (RX_SAME_GRID_FROM): its tile list from the edge stamps that the pass before it left
@@ -837,7 +866,7 @@ __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int til
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);
   const int t = first + lane;
-  if ((uint32_t)t <= list_cap) tile_list[4 + 2 * (size_t)list_cap + t] = 0u;      // queued marks (and the dummy slot)
+  if ((uint32_t)t <= list_cap) tile_list[RL_HDR + 2 * (size_t)list_cap + t] = 0u;      // queued marks (and the dummy slot)
   bool run = false;
   if (t < tilesX * tilesY) {
     const int tx = t % tilesX, ty = t / tilesX;
@@ -855,11 +884,11 @@ __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int til
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
   base = __shfl(base, 0, 64);
-  if (run) tile_list[4 + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)t;
+  if (run) tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)t;
 }
 
 // words of scratch relax_pass wants for its tile lists
-size_t relax_list_words(int h, int w) { return 4 + 3 * relax_tiles(h, w) + 64; }      // lengths, two entry arrays, queued marks (+ dummy)
+size_t relax_list_words(int h, int w) { return RL_HDR + 3 * relax_tiles(h, w) + 64; }      // header, two entry arrays, queued marks (+ dummies)
 
 // capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column; the 128 x 64 grid of the
 // same-grid passes has its own count

@@ -116,6 +116,23 @@ static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe)
               if (n != t) { cur[i] = n; changed = 1; }
             }
         }
+      } else if (op == 'c') {
+        /* both column scans in one phase: what enters a band from above / below comes through the OTHER bands as they were
+         * when the phase started; inside the band first the rows downwards, then upwards */
+        memcpy(beg, cur, cells * 4);
+        for (int x = 1; x <= tw; ++x) {
+          static uint32_t e_dn[4096], e_up[4096];
+          uint32_t v = beg[0 * P + x];
+          for (int y = 1; y <= th; ++y) { if ((y - 1) % PS == 0) e_dn[(y - 1) / PS] = v; const int i = y * P + x; v = med3(bs[i] > beg[i] ? beg[i] : bs[i], v + 1u, beg[i]); }
+          v = beg[(th + 1) * P + x];
+          for (int y = th; y >= 1; --y) { if (y % PS == 0) e_up[(y - 1) / PS] = v; const int i = y * P + x; v = med3(bs[i] > beg[i] ? beg[i] : bs[i], v + 1u, beg[i]); }
+          for (int bnd = 0; bnd < th / PS; ++bnd) {
+            uint32_t w = e_dn[bnd];
+            for (int y = bnd * PS + 1; y <= bnd * PS + PS; ++y) { const int i = y * P + x; const uint32_t n = med3(bs[i], w + 1u, cur[i]); if (n != cur[i]) { cur[i] = n; changed = 1; } w = n; }
+            w = e_up[bnd];
+            for (int y = bnd * PS + PS; y >= bnd * PS + 1; --y) { const int i = y * P + x; const uint32_t n = med3(bs[i], w + 1u, cur[i]); if (n != cur[i]) { cur[i] = n; changed = 1; } w = n; }
+          }
+        }
       } else if (op == 'd' || op == 'u') {
         for (int x = 1; x <= tw; ++x)
           for (int k2 = 0; k2 < th; ++k2) {
@@ -229,7 +246,7 @@ int main(int argc, char **argv) {
   for (size_t p = 0; p < n; ++p) sum += key[p] * (uint64_t)(p % 1000003 + 1);
   /* vector instructions per wave (ws_relax.hip, ISA counts): a patch sweep ~90, the row scans of a wave's 4 rows ~220, a
    * column scan ~100; per tile run the load / write-back / flag epilogue ~300 */
-  const double cost = 90.0 * (g_ops['D'] + g_ops['R'] + g_ops['U'] + g_ops['L']) + 220.0 * (g_ops['r'] + g_ops['l']) + 100.0 * (g_ops['d'] + g_ops['u']) + 480.0 * (g_ops['V'] + g_ops['A']) + 300.0 * runs;
+  const double cost = 90.0 * (g_ops['D'] + g_ops['R'] + g_ops['U'] + g_ops['L']) + 220.0 * (g_ops['r'] + g_ops['l']) + 100.0 * (g_ops['d'] + g_ops['u']) + 120.0 * g_ops['c'] + 480.0 * (g_ops['V'] + g_ops['A']) + 300.0 * runs;
   printf("cost %7.1f M  ", cost / 1e6);
   printf("tile %4d x %4d cap %d %-12s: passes %5ld  tile runs %8ld (%.1f per tile)  rounds %8ld (%.1f per tile)  slot waves %ld  checksum %llx\n", tw, th,
          cap, recipe, passes, runs, (double)runs / ((double)tx * ty), g_rounds, (double)g_rounds / ((double)tx * ty), waves, (unsigned long long)sum);
