@@ -49,6 +49,21 @@ constexpr int FLAG_SLOT = NSTRIPE * STRIPE_STRIDE;   // words per slot
 // bytes.  This gives each XCD one contiguous span of tile indices instead (tile rows, in row-major
 // order), so a tile's neighbours run on the same L2 at about the same time.  Bijective on [0, n).
 #ifdef __HIPCC__
+// Inclusive prefix sum over the 64 lanes of a wave without LDS: four DPP row shifts inside the rows of 16 lanes (`old` = 0:
+// a lane with nothing before it adds nothing), then the rows' totals by DPP row broadcasts (GFX9: row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3).  __shfl_up is a ds_bpermute: six dependent LDS round trips for the same sum.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+#define WS_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false)
+  WS_DPP_ADD(0x111, 0xF);      // row_shr:1
+  WS_DPP_ADD(0x112, 0xF);      // row_shr:2
+  WS_DPP_ADD(0x114, 0xF);      // row_shr:4
+  WS_DPP_ADD(0x118, 0xF);      // row_shr:8
+  WS_DPP_ADD(0x142, 0xA);      // row_bcast:15
+  WS_DPP_ADD(0x143, 0xC);      // row_bcast:31
+#undef WS_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ uint32_t xcd_span_index(uint32_t b, uint32_t n) {
   constexpr uint32_t XCDS = 8;
   const uint32_t per = n / XCDS;

@@ -331,11 +331,7 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
   // lane l owns words 4l .. 4l+3 of the chunk: exclusive scan of their popcounts = seeds before them
   const u32x4_z w = *reinterpret_cast<const u32x4_z *>(&row[lane * 4]);
   const uint32_t c0 = __popc(w.x), c1 = __popc(w.y), c2 = __popc(w.z), cnt = c0 + c1 + c2 + __popc(w.w);
-  uint32_t incl = cnt;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
+  const uint32_t incl = wave_inclusive_sum(cnt);
   uint32_t b0 = (uint32_t)lo + incl - cnt;
   // a stack of slices (slice_px % 128 == 0: a lane's four words lie in one slice): list indices count from the slice's first seed
   if (slice_first) {      // (clamped twice over for lists that are not what they should be: the slice index and the difference)
@@ -1022,11 +1018,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   // (64 lanes x 16 pixels) and a count word -- no reservation atomic, no barrier, no cross-wave offsets
   // (a returning atomicAdd per workgroup kept all four waves waiting ~1.5 us)
   const uint32_t cnt = __popc(refmask);
-  uint32_t incl = cnt;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
+  const uint32_t incl = wave_inclusive_sum(cnt);
   const size_t region = (size_t)blockIdx.x * (NTHREADS / 64) + wave;
   if (lane == 63) ref_count[region] = incl;
   if (refmask) {
@@ -1293,11 +1285,7 @@ __global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict_
     const uint32_t m = nibbles[((size_t)y * segs + seg) * 256 + threadIdx.x];
     const uint32_t c = __popc(m);
     // exclusive prefix of c inside the wave, then across the 4 waves
-    uint32_t incl = c;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
+    const uint32_t incl = wave_inclusive_sum(c);
     __syncthreads();                               // s_wave of the previous step has been read
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();

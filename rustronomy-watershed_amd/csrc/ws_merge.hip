@@ -293,7 +293,7 @@ __global__ void k_fold_and_add(const uint32_t *__restrict__ hooked, const uint32
     // the same word); what is left after them -- early levels: every lane another lake -- adds for itself
     for (int round = 0; round < 4 && todo != 0; ++round) {
       const int leader = (int)__builtin_ctzll(todo);
-      const uint32_t r0 = __shfl(r, leader, 64);
+      const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);      // (v_readlane: no LDS round trip; leader is wave uniform)
       const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
       if (lane == leader) atomicAdd(&size[r0], (uint32_t)__popcll(same));
       todo &= ~same;
