@@ -415,6 +415,9 @@ def run(args):
         if extras and args.engine == "fused":
             del labels
             out["secondary"] = secondary_smooth(eng, torch, H)
+            # the same at other correlation lengths (4 px: ~680 k seeds, short floods; 256 px: one seed, one flood over the plane)
+            out["secondary"]["other_correlation_lengths"] = {
+                str(c): {k: v for k, v in secondary_smooth(eng, torch, H, corr=c).items() if k in ("ms", "relax_passes")} for c in (4, 16, 256)}
             torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(pkg, H, W)
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1, args.cpu_runs) if (world == 1 and args.cpu_size > 0 and not args.no_extras) else None
