@@ -242,6 +242,34 @@ int main(int argc, char **argv) {
     waves += (ran + slots - 1) / slots;
     uint32_t *tt = pending; pending = pnext; pnext = tt;
   }
+  if (getenv("SIM_SEAM_REPORT")) {
+    /* key[] is the fixpoint now.  Replay pass 0 alone and report how far from the nearest tile seam the pixels are that it
+     * leaves wrong: what a repair pass confined to bands along the seams would have to reach. */
+    uint32_t *truth = malloc(n * 4);
+    memcpy(truth, key, n * 4);
+    for (size_t p = 0; p < n; ++p) key[p] = KEY_INF;
+    for (size_t i = 0; i < ns; ++i) key[seeds[i]] = 0;
+    memcpy(snap, key, n * 4);
+    for (int j = 0; j < ty; ++j)
+      for (int i = 0; i < tx; ++i) run_tile(i * tw, j * th, tw, th, cap, recipe);
+    long hist[64] = {0}, wrong = 0;
+    for (int y = 0; y < N; ++y)
+      for (int x = 0; x < N; ++x) {
+        const size_t p = (size_t)y * N + x;
+        if (key[p] == truth[p]) continue;
+        ++wrong;
+        int dx = x % tw, dy = y % th;
+        dx = dx < tw - 1 - dx ? dx : tw - 1 - dx;
+        dy = dy < th - 1 - dy ? dy : th - 1 - dy;
+        const int d = dx < dy ? dx : dy;
+        ++hist[d < 63 ? d : 63];
+      }
+    printf("after pass 0 alone (cap %d, %s): %ld of %zu pixels not final (%.3f %%); by distance to the nearest seam:", cap, recipe, wrong, n, 100.0 * wrong / n);
+    long cum = 0;
+    for (int d = 0; d < 64; ++d) { cum += hist[d]; if (hist[d]) printf(" %d:%ld", d, hist[d]); }
+    printf("\n");
+    memcpy(key, truth, n * 4);
+  }
   uint64_t sum = 0;
   for (size_t p = 0; p < n; ++p) sum += key[p] * (uint64_t)(p % 1000003 + 1);
   /* vector instructions per wave (ws_relax.hip, ISA counts): a patch sweep ~90, the row scans of a wave's 4 rows ~220, a
