@@ -138,6 +138,20 @@ def test_tiled_hip_three_ranks_smooth_field_and_corridor():
     assert rounds > 20
 
 
+def test_tiled_hip_two_ranks_long_range_floods_cross_the_blocks():
+    # few seeds on a smooth field: single floods cross the block boundary and travel hundreds of rows on the other side, so a
+    # halo repair (ws_block_relax_halo, passes from 4 on) runs well into the one-grid passes of 128 x 64 tiles (tile lists by
+    # ticket, appends per workgroup) with a halo row at the top / bottom of the plane
+    img = cases.smooth_field(1300, 1100, 31, octaves=6)
+    seeds = ol.find_local_minima(img)
+    seeds = seeds[:: max(len(seeds) // 4, 1)][:4]
+    got, rounds = _run(img, seeds, 2)
+    assert (got == ol.segment_arrival(img, seeds)).all()
+    assert rounds >= 2
+    got, _ = _run(img, ol.find_local_minima(img), 3)
+    assert (got == ol.segment_arrival(img, ol.find_local_minima(img))).all()
+
+
 def _merge_worker(rank, world, port, img, seeds, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
