@@ -351,7 +351,7 @@ def run(args):
                 "tiles_run_per_step": round(agg["tiles_run_relax"] / args.steps, 1),
                 "tile_sweep_iterations_per_step": round(agg["relax_tile_iterations"] / args.steps, 1),
                 "algorithmic_bytes_per_launch": int(k_bytes_per_launch),
-                "note": "achieved/frac: bytes THIS kernel asks for (5 B per pixel of every 256x32 tile run in passes >= 1, "
+                "note": "achieved/frac: bytes THIS kernel asks for (5 B per pixel of every tile run in passes >= 1 -- 8192-pixel tiles; the 256x8 bands of the seam repair count a quarter -- "
                         "counted on the device, re-runs included; 1.125 B per pixel in pass 0; 4 B per pixel written once) over "
                         "its HIP-event time -- DESIGN.md section 5.  The whole-transform figure against unavoidable bytes is "
                         "frac_compulsory.",

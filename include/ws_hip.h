@@ -110,7 +110,7 @@ typedef struct ws_stats {
   uint32_t resolve_passes;    /* fused engine: global label-resolve passes launched */
   uint32_t sweep_steps;       /* sweep engine: flood steps launched */
   uint32_t merge_levels;      /* merging: levels with at least one union */
-  uint64_t tiles_run_relax;   /* tiles that actually did work, summed over passes */
+  uint64_t tiles_run_relax;   /* tiles that actually did work, summed over passes, in units of 8192 pixels (a seam band of 256 x 8 is a quarter) */
   uint64_t tiles_run_resolve;
   float ms_relax;             /* HIP-event time per kernel class; filled only when */
   float ms_resolve;           /* profiling is enabled with ws_ctx_set_profiling     */
@@ -157,6 +157,10 @@ int ws_ctx_synchronize(ws_ctx *ctx);
 /* ws_segment_batch_device stacks at most this many pixels into one transform (the stack needs 9 bytes per pixel of
  * context workspace); larger batches run as several stacks.  0 restores the default, 2^31 - 1, which is also the cap. */
 int ws_ctx_set_batch_pixel_limit(ws_ctx *ctx, size_t max_px);
+/* The segmenting transform of a plane with at least this many pixels repairs the seams of its first relaxation pass with
+ * bands and strips instead of a second pass over every tile (same labels either way).  0 restores the
+ * default, 2^24: smaller planes are bound by launch gaps and gain nothing.  (Tests lower it to cover the path on small planes.) */
+int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
 
 /* TransformBuilder::build_segmenting / build_merging validation (lib.rs:999-1004, 1026-1030). */
 int ws_options_default(ws_options *out);          /* lib.rs:936-946: max 254, no edge correction */

@@ -96,6 +96,7 @@ extern "C" {
     pub fn ws_ctx_get_stats(ctx: *const ws_ctx, out: *mut ws_stats) -> c_int;
     pub fn ws_ctx_synchronize(ctx: *mut ws_ctx) -> c_int;
     pub fn ws_ctx_set_batch_pixel_limit(ctx: *mut ws_ctx, max_px: usize) -> c_int;
+    pub fn ws_ctx_set_seam_repair_min_pixels(ctx: *mut ws_ctx, min_px: usize) -> c_int;
     pub fn ws_options_default(out: *mut ws_options) -> c_int;
     pub fn ws_options_validate(opt: *const ws_options) -> c_int;
 

@@ -118,6 +118,9 @@ class Context:
     def set_batch_pixel_limit(self, max_px):
         self.check(_ffi.lib().ws_ctx_set_batch_pixel_limit(self._h, int(max_px)))
 
+    def set_seam_repair_min_pixels(self, min_px):
+        self.check(_ffi.lib().ws_ctx_set_seam_repair_min_pixels(self._h, int(min_px)))
+
 
 _default_ctx = None
 

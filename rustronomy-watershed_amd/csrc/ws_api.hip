@@ -65,6 +65,7 @@ struct ws_ctx {
   bool block_ready = false;       // ws_block_begin has built the seed tables of a row block of block_h x block_w pixels
   size_t block_h = 0, block_w = 0;
   size_t batch_max_px = 0x7FFFFFFFull;      // largest stack of slices run as one transform (ws_ctx_set_batch_pixel_limit)
+  size_t seam_min_px = (size_t)1 << 24;     // smallest plane whose pass 1 is a seam repair (ws_ctx_set_seam_repair_min_pixels)
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
   // the optimistic part of a transform (seed tables, first passes, gated resolve, read-backs) as a replayable graph
   struct GraphKey {
@@ -370,7 +371,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     hipError_t e = seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
                                relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
-      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list);
+      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px);
     const uint32_t last = GRAPH_PASSES - 1;
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
@@ -440,7 +441,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto launch_pass = [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list);
+                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list, c->seam_min_px);
   };
   if (graph_mode != 0) {
     // the graph ran seed tables, passes 0 .. GRAPH_PASSES - 1, the gated resolve and the read-backs
@@ -456,7 +457,8 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     rc = pass_loop(c, flags, relax_tiles(ph, pw), &c->stats.relax_passes, launch_pass, true, 5, speculate, &converged_at);
     if (rc) return rc;
   }
-  c->stats.launches_relax = c->stats.relax_passes;
+  // (a seam repair is two launches for pass 1: bands, strips)
+  c->stats.launches_relax = c->stats.relax_passes + (c->stats.relax_passes >= 2 && relax_uses_seam_repair(ph, pw, tables, slice_h, padded, c->seam_min_px) ? 1u : 0u);
 
   // no host round trip here: the error words are read once, after the resolve launches are queued
   if (two_launch) {
@@ -480,10 +482,12 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   } else if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
     HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_STATS], flags + FLAG_STATS, 2 * FLAG_SLOT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t quarter_tiles = 0;      // k_relax counts 2048-pixel units: the seam repair's bands are quarter tiles
     for (int i = 0; i < NSTRIPE; ++i) {
-      c->stats.tiles_run_relax += c->pinned[FLAG_STATS + i * STRIPE_STRIDE];
+      quarter_tiles += c->pinned[FLAG_STATS + i * STRIPE_STRIDE];
       c->stats.relax_tile_iterations += c->pinned[FLAG_STATS + FLAG_SLOT + i * STRIPE_STRIDE];
     }
+    c->stats.tiles_run_relax += (quarter_tiles + 2) / 4;
   } else {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
@@ -787,6 +791,13 @@ int ws_ctx_get_stats(const ws_ctx *c, ws_stats *out) {
 int ws_ctx_set_batch_pixel_limit(ws_ctx *c, size_t max_px) {
   if (!c) return WS_ERR_BAD_ARG;
   c->batch_max_px = max_px == 0 ? 0x7FFFFFFFull : std::min<size_t>(max_px, 0x7FFFFFFFull);
+  return WS_OK;
+}
+
+int ws_ctx_set_seam_repair_min_pixels(ws_ctx *c, size_t min_px) {
+  if (!c) return WS_ERR_BAD_ARG;
+  c->seam_min_px = min_px == 0 ? (size_t)1 << 24 : min_px;
+  ++c->buffer_generation;      // a captured graph holds the launches of the other flow
   return WS_OK;
 }
 

@@ -331,7 +331,7 @@ __device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uin
   // and the checked sweep's)
 }
 
-template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false>
+template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false, int SEAM = 0>
 __global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
 const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
@@ -350,6 +350,14 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   constexpr int LX = SPLIT ? 32 : 64;             // lanes across a tile row
   constexpr int NB = SPLIT ? 2 * NW : NW;         // bands of RX_P rows
   constexpr int TW = LX * RX_P, TH = NB * RX_P;
+  // SEAM (relax_pass, seam repair: the pass after pass 0 of a transform that starts from its seeds).  What a pass leaves
+  // wrong lies within a few pixels of its tile borders, so the pass after pass 0 only has to look along those:
+  //   SEAM 1  a tile is 256 x 8 pixels (NW = 2) astride a horizontal seam of the 256 x 32 grid, rows 32 (ty + 1) - 4 ...;
+  //   SEAM 2  a tile is a 32-row slice of 32 vertical seams: lanes 2j and 2j + 1 hold the 8 columns astride seam
+  //           32 tile_x + j + 1 (x = 256 times that), and no stamp crosses from one lane PAIR to the next.
+  // A seam tile iterates to its fixpoint and raises, in the stamp word that the next pass of the anchored grid reads, the
+  // flag of every 256 x 32 tile that holds a pixel next to a changed outer row or column of it.  (otherX: that array's pitch.)
+  constexpr int SEAM_PY = 32, SEAM_PX = 256, SEAM_HALF = SEAM == 1 ? TH / 2 : 4;
   // row 0: halo above the tile; rows 1+2w / 2+2w: top / bottom row of band w; last row: halo below
   __shared__ __attribute__((aligned(16))) uint32_t sRow[2 * NB + 2][TW];
   // the tile border as loaded (top row, bottom row, left column, right column): compared with the
@@ -400,8 +408,24 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     if (todo == 0) return;
   } else {
     const int tx = first % tilesX, ty = first / tilesX;
-    if (tx * TW - (shifted ? TW / 2 : 0) >= W || ty * TH - (shifted ? TH / 2 : 0) >= H) return;
-    if (pass != 0) {       // the same test as relax_todo, on scalars (workgroup uniform)
+    // (a seam whose tiles on both sides have asked for a re-run already -- pass 0 stopped at its round cap there: a smooth
+    // map -- is left to them: on such maps the repair would be 64 us of sweeps that the re-runs undo)
+    if (SEAM == 1) {
+      if (tx * TW >= W || (ty + 1) * SEAM_PY >= H) return;
+      // (a tile that asked for its re-run is work for pass 2: this pass must not look like a fixpoint to the host -- pass 0
+      // cannot say so itself, its launch clears this pass's convergence slot)
+      const bool fa = stamps_cur[((size_t)ty * otherX + tx + 1) * 4 + 2] == pass + 1, fb = stamps_cur[((size_t)(ty + 1) * otherX + tx + 1) * 4 + 2] == pass + 1;
+      if ((fa || fb) && threadIdx.x == 0) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + (blockIdx.x % NSTRIPE) * STRIPE_STRIDE] = 1u;
+      if (fa && fb) return;
+    } else if (SEAM == 2) {
+      if (ty * TH - (shifted ? TH / 2 : 0) >= H || (tx * 32 + 1) * SEAM_PX >= W) return;
+      const int l = threadIdx.x & 63;
+      const int sxl = (tx * 32 + (l >> 1) + 1) * SEAM_PX;
+      const bool settled = sxl >= W || stamps_cur[((size_t)((ty * TH) / SEAM_PY) * otherX + (sxl / SEAM_PX - 1 + (l & 1)) + 1) * 4 + 2] == pass + 1;
+      if (__builtin_amdgcn_ballot_w64(settled) == ~0ull) return;
+    }
+    else if (tx * TW - (shifted ? TW / 2 : 0) >= W || ty * TH - (shifted ? TH / 2 : 0) >= H) return;
+    if (SEAM == 0 && pass != 0) {       // the same test as relax_todo, on scalars (workgroup uniform)
       bool run = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -446,10 +470,12 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   const int band = SPLIT ? (tid >> 6) * 2 + (lane >> 5) : tid >> 6;             // four-row band of the tile
   const int tile = CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[RL_HDR + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first;
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
-  const int x0 = tile_x * TW - (shifted ? TW / 2 : 0), y0 = tile_y * TH - (shifted ? TH / 2 : 0);
+  const int x0 = SEAM ? tile_x * TW : tile_x * TW - (shifted ? TW / 2 : 0);
+  const int y0 = SEAM == 1 ? (tile_y + 1) * SEAM_PY - SEAM_HALF : tile_y * TH - (shifted ? TH / 2 : 0);
+  const int seam_x = (tile_x * 32 + (lane >> 1) + 1) * SEAM_PX;      // SEAM 2: this lane pair's seam (outside the plane: no seam)
 
   WS_STAMP(0);
-  const int gx0 = x0 + xl * RX_P, gyb = y0 + band * RX_P;
+  const int gx0 = SEAM == 2 ? (seam_x < W ? seam_x - SEAM_HALF + (lane & 1) * RX_P : W) : x0 + xl * RX_P, gyb = y0 + band * RX_P;
   if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
   // List mode: entries are handed out by ticket, not in strides of the grid -- tile runs last 8 to 20 us, and with a fixed
   // share a pass ended with most workgroups gone and a few still on their third tile.  The ticket for the NEXT entry is
@@ -463,13 +489,15 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // (patches outside the plane read a clamped address and are masked afterwards: with W % 4 == 0 a
   // patch is either wholly inside or wholly outside)
   // (pad: the image is the caller's unpadded one, read through padded_img_index -- byte loads)
-  const bool fast = !pad && W >= RX_P && ((x0 >= 0 && x0 + TW <= W) || (W & 3) == 0) &&
+  const bool fast = !pad && W >= RX_P && ((SEAM != 2 && x0 >= 0 && x0 + TW <= W) || (W & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
   const int gxc0 = min(max(gx0, 0), max(W - RX_P, 0));
   // tile halo columns: the left half of a row's lanes fetch the column left of the tile, the right half the one right
   // of it; only the first / last lane of a row ever use the value (as the DPP `old` operand)
-  const int xh = min(max(xl < LX / 2 ? x0 - 1 : x0 + TW, 0), W - 1);
-  const bool xh_ok = xl < LX / 2 ? x0 > 0 : x0 + TW < W;
+  // (SEAM 2: every lane is the first or the last of its pair's row)
+  const int xh_raw = SEAM == 2 ? ((lane & 1) ? gx0 + RX_P : gx0 - 1) : (xl < LX / 2 ? x0 - 1 : x0 + TW);
+  const int xh = min(max(xh_raw, 0), W - 1);
+  const bool xh_ok = SEAM == 2 ? (xh_raw >= 0 && xh_raw < W && seam_x < W) : (xl < LX / 2 ? x0 > 0 : x0 + TW < W);
   const int gy_halo_raw = band == 0 ? y0 - 1 : y0 + TH;
   const int gy_halo = min(max(gy_halo_raw, 0), H - 1);
   u32x4_t halo_row;
@@ -549,7 +577,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // Workgroup uniform: the tile and its halo ring lie strictly inside the image (and the image is not a stack of
   // slices) -- every pixel is in the plane and interior, none of the masks below can bite.  These kernels are VALU-bound
   // (VALUBusy 76-84 %, profiles/), and the masks were ~8 ops per pixel of a tile run's ~60.
-  const bool inner = SH == H && x0 >= 1 && x0 + TW <= W - 1 && y0 >= 1 && y0 + TH <= H - 1;
+  const bool inner = SEAM != 2 && SH == H && x0 >= 1 && x0 + TW <= W - 1 && y0 >= 1 && y0 + TH <= H - 1;
   if (!inner) {
     // row inside its slice: the four rows of a patch are all above the plane or all from row 0 on
     const int ry0 = (SH == H || gyb < 0) ? gyb : gyb % SH;
@@ -604,6 +632,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       Lh[r] = lane_left(Lh[r], T[r][3]);
       Rh[r] = lane_right(Rh[r], T[r][0]);
       if (SPLIT) { Lh[r] = lane == 32 ? halo[r] : Lh[r]; Rh[r] = lane == 31 ? halo[r] : Rh[r]; }
+      if (SEAM == 2) { Lh[r] = (lane & 1) ? Lh[r] : halo[r]; Rh[r] = (lane & 1) ? halo[r] : Rh[r]; }
     }
   };
   {
@@ -614,7 +643,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   }
   if (band == 0) *reinterpret_cast<u32x4_t *>(&sInitRow[0][xl * RX_P]) = u32x4_t{T[0][0], T[0][1], T[0][2], T[0][3]};
   if (band == NB - 1) *reinterpret_cast<u32x4_t *>(&sInitRow[1][xl * RX_P]) = u32x4_t{T[3][0], T[3][1], T[3][2], T[3][3]};
-  if (xl == 0 || xl == LX - 1) {
+  uint32_t init_col[RX_P];          // SEAM 2: this lane's outer column as loaded (every lane has one)
+  if (SEAM == 2) {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) init_col[r] = T[r][(lane & 1) ? 3 : 0];
+  } else if (xl == 0 || xl == LX - 1) {
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) sInitCol[xl == 0 ? 0 : 1][band * RX_P + r] = T[r][xl == 0 ? 0 : 3];
   }
@@ -757,21 +790,58 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][xl * RX_P]);
       if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit | 128u;
     }
-    if (xl == 0 || xl == LX - 1) {
+    if (SEAM == 2) {
+      // a lane pair raises its own flags: the anchored tile that holds this lane's columns (left of the seam for the even
+      // lane, right of it for the odd one), and that tile's neighbour above / below when the slice's first / last row changed
+      bool col = false;
+#pragma unroll
+      for (int r = 0; r < RX_P; ++r) col |= init_col[r] != T[r][(lane & 1) ? 3 : 0];
+      col |= unfinished;      // stopped at the round cap: the tiles on both sides of every seam of this slice look again
+      const int fx = seam_x / SEAM_PX - 1 + (lane & 1);
+      const uint32_t mark = pass + 1;
+      if (seam_x < W) {      // (anchored tile rows are SEAM_PY pixel rows; a slice lies in one of them)
+        if (col && gyb >= 0 && gyb < H) { stamps_cur[((size_t)(gyb / SEAM_PY) * otherX + fx) * 4 + 3] = mark; e |= 1u; }
+        if ((e & 64u) && y0 > 0) { stamps_cur[((size_t)((y0 - 1) / SEAM_PY) * otherX + fx) * 4 + 3] = mark; e |= 1u; }
+        if ((e & 128u) && y0 + TH < H) { stamps_cur[((size_t)((y0 + TH) / SEAM_PY) * otherX + fx) * 4 + 3] = mark; e |= 1u; }
+      }
+      e &= 1u | 16u;
+    } else if (xl == 0 || xl == LX - 1) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r)
         if (sInitCol[xl == 0 ? 0 : 1][band * RX_P + r] != T[r][xl == 0 ? 0 : 3]) e |= qbit | (xl == 0 ? 256u : 512u);
     }
   }
+  // (SEAM 2, a slice that stopped at its round cap: also the lanes that changed nothing ask for their tile's re-run)
+  if (SEAM == 2 && unfinished && !any_lower && seam_x < W && gyb >= 0 && gyb < H) {
+    stamps_cur[((size_t)(gyb / SEAM_PY) * otherX + (seam_x / SEAM_PX - 1 + (lane & 1))) * 4 + 3] = pass + 1;
+    e |= 1u;
+  }
   if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
-  if (unfinished && write_same) e |= 32u;
+  if (unfinished && (write_same || SEAM == 1 || chunk == 3)) e |= 32u;      // (chunk == 3: pass 0 of a seam-repair transform)
   if (e) atomicOr(&s_edges, e);
   __syncthreads();
   if (tid == 0) {
     const uint32_t ed = s_edges;
     const uint32_t stripe = (blockIdx.x % NSTRIPE) * STRIPE_STRIDE;
-    if (ed) {
+    if (SEAM) {
+      // SEAM 1: the tile above the seam holds the pixels over this tile's first row, the tile below those under its last;
+      // what its first / last COLUMN changed lies inside a vertical strip, which runs after the bands.  (SEAM 2: the lanes
+      // have stored their flags themselves.)
+      bool any = SEAM == 2 && (ed & 1u) != 0u;
+      if (SEAM == 1) {      // (bit 5: the band stopped at its round cap)
+        if (ed & (64u | 32u)) { stamps_cur[((size_t)tile_y * otherX + tile_x) * 4 + 3] = pass + 1; any = true; }
+        if (ed & (128u | 32u)) { stamps_cur[((size_t)(tile_y + 1) * otherX + tile_x) * 4 + 3] = pass + 1; any = true; }
+      }
+      if (any) pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT + stripe] = 1u;
+      if (ed) pf.any_change[stripe] = 1u;
+    } else if (ed) {
       const size_t t = (size_t)tile_y * tilesX + tile_x;
+      // pass 0 of a seam-repair transform (chunk == 3) that stopped at its round cap: nobody reads this pass's own stamps
+      // (the bands and strips look at every seam anyway), so the tile asks for its re-run where pass 2 will look -- the
+      // word of the OTHER stamp array that the bands and strips use for the same purpose
+      // (pass 2 runs anchored tile (x, y) for word 3 of entry (x, y) or word 2 of entry (x + 1, y): the first is the bands'
+      // and strips', the second this one's, so that they can tell a tile pass 0 gave up on from one a band has flagged)
+      if (!CHUNKED && chunk == 3 && (ed & 32u)) const_cast<uint32_t *>(stamps_prev)[((size_t)tile_y * otherX + tile_x + 1) * 4 + 2] = pass + 2;
       if (write_same) {      // the next pass runs on this grid (relax_todo, read_same)
         if (ed & 33u) stamps_cur[t * 4 + 0] = (pass + 1) | (ed & 1u ? ST_BORDER : 0u) | (ed & 32u ? ST_SELF : 0u);
         if (ed & 2u) stamps_cur[t * 4 + 1] = (pass + 1) | ST_BORDER;
@@ -803,7 +873,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       pf.any_change[stripe] = 1u;
     }
     if (pf.stats) {            // profiling only: striped counters, one per 64-byte line
-      atomicAdd(&pf.stats[stripe], 1u);
+      atomicAdd(&pf.stats[stripe], (uint32_t)(TW * TH / 2048));      // in quarter tiles: a 256 x 8 band is one, every other tile four (ws_api.hip divides)
       atomicAdd(&pf.stats[FLAG_SLOT + stripe], iters);
     }
   }
@@ -926,10 +996,16 @@ hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w
   return hipGetLastError();
 }
 
+// Does a transform of this plane, started from its seeds, repair pass 0's seams with bands and strips (relax_pass)?
+bool relax_uses_seam_repair(int h, int w, bool seed_bits, int slice_h, bool padded, size_t seam_min_px) {
+  const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + RX_NW * RX_P - 1) / (RX_NW * RX_P);
+  return seed_bits && !padded && (slice_h <= 0 || slice_h == h) && (w & 3) == 0 && ax >= 2 && ay >= 2 && (size_t)h * (size_t)w >= seam_min_px;
+}
+
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded,
-                      uint32_t *tile_list) {
+                      uint32_t *tile_list, size_t seam_min_px) {
   const int th = RX_NW * RX_P;
   const int pad = padded ? 1 : 0;
   // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
@@ -962,7 +1038,11 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     const char *e = tuning_env("WS_RELAX_P0_ROUNDS");        // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 2u;
   }();
-  if (pass == 0 && p0_rounds < max_iters) max_iters = p0_rounds;
+  static const bool no_seam = tuning_env("WS_RELAX_NO_SEAM") != nullptr;      // A/B knob, tools/ only
+  const bool seam_flow = !no_seam && seed_labels != nullptr && relax_uses_seam_repair(h, w, seed_bits, slice_h, padded, seam_min_px);      // (below)
+  constexpr uint32_t SEAM_P0_ROUNDS = 4;
+  const uint32_t p0_cap = seam_flow ? SEAM_P0_ROUNDS : p0_rounds;
+  if (pass == 0 && p0_cap < max_iters) max_iters = p0_cap;
   // Late passes (the long-range regime of smooth maps: a few hundred tiles along the flood fronts per pass) end when their
   // SLOWEST tile ends, and a tile that the front is crossing diagonally can take a dozen rounds.  Capping the rounds lets a
   // pass end after the typical tile's work: a capped tile raises all four quadrant flags (like a capped pass-0 tile), so
@@ -993,10 +1073,34 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     const char *e = tuning_env("WS_RELAX_CHUNK_FROM");      // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : 3u;
   }();
+  // Seam repair (k_relax, SEAM): a transform that starts from its seeds runs pass 0 to every tile's own fixpoint and then,
+  // as "pass 1", 8-row bands astride the horizontal seams of the 256 x 32 grid and 8-column strips astride the vertical
+  // ones -- a third of the pixels of the shifted grid's pass, which it replaces -- and those raise the flags that pass 2
+  // reads.  Planes it is not offered for (odd widths, stacks of slices, the virtual halo, planes of a tile or two) keep
+  // the alternating grids from pass 1 on.
+  // (8192^2 bench field: pass 0 141 -> 168 us, pass 1 117 us -> bands 34 + strips 30 us, the later passes as before: 0.622 ->
+  // 0.595 ms per transform; 2048^2: 0.131 -> 0.137 ms, one more launch in a transform that is all launch gaps -- hence the
+  // size threshold.  Wider bands, smaller strip slices and a second, shifted strip launch were measured too: no better,
+  // profiles/r2_v6_seam_ab.log.)
+  // Round caps of that flow: three rounds bring a tile of the bench field to its own fixpoint (the third finds nothing to
+  // do); a tile, band or strip slice of a smooth map that is still moving then asks for a re-run in pass 2 instead of
+  // carrying a flood across its 256 columns sweep by sweep.
+  constexpr uint32_t SEAM_REPAIR_ROUNDS = 4;
+  if (seam_flow && pass == 1) {
+    k_relax<2, false, false, false, false, 1><<<ax * (ay - 1), 128, 0, s>>>(img, img_stride, keys, h, w, ax, ay - 1, sx, sy, 0, 1, max_level, pass, prev, cur,
+                                                                          pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0, 0, list_cap, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int strips_x = (ax - 1 + 31) / 32;
+    k_relax<RX_NW, false, false, false, false, 2><<<strips_x * ay, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, strips_x, ay, sx, sy, 0, 1, max_level, pass,
+                                                                                       prev, cur, pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0,
+                                                                                       0, list_cap, 0);
+    return hipGetLastError();
+  }
   const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
   if (pass < chunk_from && pass < lite_from) {
-    k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
+    k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, seam_flow && pass == 0 ? 3 : 1, max_level, pass,
                                                                        prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
   } else if (pass < chunk_from) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,

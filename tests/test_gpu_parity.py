@@ -602,3 +602,38 @@ def test_level_snapshots_on_the_device_match_transform_history(pkg):
         got = eng.level_snapshot(labels, lvl).cpu().numpy().view(np.uint32)
         assert (got == levels[lvl]).all(), lvl
     assert (eng.level_snapshot(labels, 254, out=labels).cpu().numpy().view(np.uint32) == levels[254]).all()      # in place
+
+
+# ---- seam repair: pass 1 as bands and strips along the tile borders of pass 0 ---------------------------------------------
+
+@pytest.mark.parametrize("shape,kind", [((96, 520), "noise"), ((257, 1028), "noise"), ((300, 772), "smooth"), ((1000, 1300), "smooth5"),
+                                        ((64, 260), "noise"), ((33, 512), "noise"), ((640, 1024), "noise"), ((129, 2048), "smooth")])
+def test_seam_repair_flow_on_small_planes(pkg, shape, kind):
+    # planes of 2^24 pixels and more take this flow by default (test_gpu_fullsize.py, the fix-point tests above); here the
+    # threshold is lowered so that the oracle can check it: widths that are and are not multiples of the 256-pixel tile,
+    # heights that are not multiples of 32 (a last seam a few rows above the plane's end), a single seam row, one band of
+    # strips, noise and smooth fields (floods that cross many seams), several water levels, and the merging transform
+    # (whose segmenting part takes the same passes)
+    if kind == "noise":
+        img = cases.field(*shape, 77)
+    else:
+        img = cases.smooth_field(*shape, 41, octaves=5 if kind == "smooth5" else 4)
+    seeds = ol.find_local_minima(img)
+    ws = _seg(pkg, pkg.ENGINE_FUSED)
+    ws._ctx().set_seam_repair_min_pixels(1)
+    try:
+        for _ in range(2):      # the second call replays a captured graph
+            got = ws.transform(img, seeds)
+            assert (got == ol.segment_arrival(img, seeds)).all(), (shape, kind)
+            st = ws._ctx().stats()
+            assert st["launches_relax"] == st["relax_passes"] + 1      # pass 1 was two launches: bands, strips
+        few = seeds[:: max(len(seeds) // 3, 1)][:3]
+        assert (ws.transform(img, few) == ol.segment_arrival(img, few)).all()
+        lo = pkg.TransformBuilder.new().set_max_water_lvl(100).build_segmenting()
+        lo._ctx().set_seam_repair_min_pixels(1)
+        assert (lo.transform(img, seeds) == ol.segment_arrival(img, seeds, max_level=100)).all()
+        mg = pkg.TransformBuilder.new().build_merging()
+        mg._ctx().set_seam_repair_min_pixels(1)
+        assert (mg.transform_final(img, seeds) == ol.merge_arrival(img, seeds)).all()
+    finally:
+        ws._ctx().set_seam_repair_min_pixels(0)
