@@ -999,7 +999,9 @@ hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w
 // Does a transform of this plane, started from its seeds, repair pass 0's seams with bands and strips (relax_pass)?
 bool relax_uses_seam_repair(int h, int w, bool seed_bits, int slice_h, bool padded, size_t seam_min_px) {
   const int ax = (w + RX_TW - 1) / RX_TW, ay = (h + RX_NW * RX_P - 1) / (RX_NW * RX_P);
-  return seed_bits && !padded && (slice_h <= 0 || slice_h == h) && (w & 3) == 0 && ax >= 2 && ay >= 2 && (size_t)h * (size_t)w >= seam_min_px;
+  // (a stack of slices takes it too: slice walls are rows of pinned pixels, wherever they fall in a band or a strip slice)
+  (void)slice_h;
+  return seed_bits && !padded && (w & 3) == 0 && ax >= 2 && ay >= 2 && (size_t)h * (size_t)w >= seam_min_px;
 }
 
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,

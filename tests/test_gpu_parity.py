@@ -637,3 +637,27 @@ def test_seam_repair_flow_on_small_planes(pkg, shape, kind):
         assert (mg.transform_final(img, seeds) == ol.merge_arrival(img, seeds)).all()
     finally:
         ws._ctx().set_seam_repair_min_pixels(0)
+
+
+@pytest.mark.parametrize("s,h,w", [(3, 40, 520), (2, 64, 512), (5, 33, 772), (2, 200, 1028)])
+def test_seam_repair_flow_on_stacked_slices(pkg, s, h, w):
+    # a stack of slices through the seam repair: slice walls inside bands (a slice height that is no multiple of 32), on a
+    # seam (64), and several to a strip slice; noise and smooth slices
+    import importlib
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    eng.ctx.set_seam_repair_min_pixels(1)
+    try:
+        himgs, hseeds = _batch_case(s, h, w, 500 + s)
+        got = _run_batch(eng, himgs, hseeds)
+        for k in range(s):
+            assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k].astype(np.uint64))).all(), k
+        st = eng.stats()
+        assert st["launches_relax"] == st["relax_passes"] + 1
+        himgs = [cases.smooth_field(h, w, 90 + k, octaves=4) for k in range(s)]
+        hseeds = [ol.find_local_minima(a) for a in himgs]
+        got = _run_batch(eng, himgs, hseeds)
+        for k in range(s):
+            assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+    finally:
+        eng.ctx.set_seam_repair_min_pixels(0)
