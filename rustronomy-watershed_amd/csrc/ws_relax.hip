@@ -710,7 +710,10 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // Same sequence of sweeps as the other order minus the first three; the exit test is the same.
   for (; max_iters != 0;) {
     ++iters;
-    if (!LITE) free_sweeps(iters);
+    // (chunk == 3, pass 0 of a seam-repair transform: after two full rounds a tile of the bench field has two or three stamps
+    // left to settle -- from the third round on a round is its checked sweep alone, one sweep to settle them and one to see
+    // that nothing moves, instead of a round of four that finds nothing to do)
+    if (!LITE && !(chunk == 3 && iters > 2)) free_sweeps(iters);
     bool changed = false;
     uint32_t up[RX_P], dn[RX_P];
     {
@@ -1042,7 +1045,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }();
   static const bool no_seam = tuning_env("WS_RELAX_NO_SEAM") != nullptr;      // A/B knob, tools/ only
   const bool seam_flow = !no_seam && seed_labels != nullptr && relax_uses_seam_repair(h, w, seed_bits, slice_h, padded, seam_min_px);      // (below)
-  constexpr uint32_t SEAM_P0_ROUNDS = 4;
+  constexpr uint32_t SEAM_P0_ROUNDS = 6;      // two rounds of four sweeps, then up to four of one (k_relax, chunk == 3)
   const uint32_t p0_cap = seam_flow ? SEAM_P0_ROUNDS : p0_rounds;
   if (pass == 0 && p0_cap < max_iters) max_iters = p0_cap;
   // Late passes (the long-range regime of smooth maps: a few hundred tiles along the flood fronts per pass) end when their
