@@ -298,7 +298,7 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   return WS_OK;
 }
 
-constexpr uint32_t GRAPH_PASSES = 6;      // passes inside the graph: the first group of five and its lookahead pass
+constexpr uint32_t GRAPH_PASSES = 5;      // passes inside the graph; the resolve is gated on the last one (the bench field: pass 3 still moves a few tiles, pass 4 finds nothing -- a sixth pass was 6 us of idle launch)
 
 inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass) {
   return d_flags + FLAG_EDGE + (size_t)(pass % COUNTER_RING) * FLAG_SLOT;
