@@ -171,8 +171,11 @@ def test_random_batches_of_slices_bit_exact():
             assert got[k].shape == want.shape and (got[k] == want).all(), (case, k, s, h, w, edge, max_level)
 
 
-def test_random_call_sequences_on_one_context_bit_exact():
-    """One context on a real stream (graph capture allowed), a random sequence of segmenting / merging / batch calls
+@pytest.mark.parametrize("seam", [False, True])
+def test_random_call_sequences_on_one_context_bit_exact(seam):
+    """(seam: planes wide enough for the seam repair, its size threshold lowered to 1 pixel and now and then raised again
+    between calls, which retires the captured graphs.)
+    One context on a real stream (graph capture allowed), a random sequence of segmenting / merging / batch calls
     over a few fixed sets of device buffers whose CONTENTS change: graphs get captured, replayed, retired by other
     shapes, fed unsorted lists (the replayed tables are then wrong and the transform repeats itself), corridors that
     need more passes than a graph holds."""
@@ -185,7 +188,9 @@ def test_random_call_sequences_on_one_context_bit_exact():
     with torch.cuda.stream(torch.cuda.Stream()):
         eng = dev.DeviceEngine(0)
         sets = []
-        for (h, w, n) in ((64, 128, 300), (96, 256, 40), (40, 64, 7)):
+        if seam:
+            eng.ctx.set_seam_repair_min_pixels(1)
+        for (h, w, n) in (((64, 520, 900), (96, 772, 60), (40, 300, 7)) if seam else ((64, 128, 300), (96, 256, 40), (40, 64, 7))):
             sets.append({"h": h, "w": w, "n": n,
                          "img": torch.empty((h, w), dtype=torch.uint8, device=eng.device),
                          "seeds": torch.empty((n, 2), dtype=torch.int32, device=eng.device),
@@ -194,6 +199,8 @@ def test_random_call_sequences_on_one_context_bit_exact():
         for call in range(60):
             st = sets[int(rng.choice([0, 0, 0, 1, 1, 2]))]
             h, w, n = st["h"], st["w"], st["n"]
+            if seam and rng.integers(0, 10) == 0:
+                eng.ctx.set_seam_repair_min_pixels(int(rng.choice([0, 1])))      # 0: the default threshold (these planes: no repair)
             kind = int(rng.integers(0, 4))
             if kind == 0:
                 img = rng.integers(0, 254, (h, w), dtype=np.uint8)
