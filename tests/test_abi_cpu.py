@@ -73,7 +73,7 @@ def test_shipped_library_ignores_its_environment(pkg):
     blob = open(pkg._ffi.LIB_PATH, "rb").read()
     for knob in (b"WS_DEBUG_MAXIT", b"WS_NO_GRAPH", b"WS_NO_SPECULATION", b"WS_NO_SEED_TABLES", b"WS_NO_BATCH_STACK",
                  b"WS_BATCH_MAX_PX", b"WS_RELAX_P0_ROUNDS", b"WS_RELAX_CHUNK_FROM", b"WS_PAINT_STEPS", b"WS_RELAX_LATE_CAP",
-                 b"WS_RELAX_EARLY_CAP", b"WS_RELAX_NO_SPLIT", b"WS_RELAX_LIST_FROM", b"WS_RELAX_SAME_GRID_FROM", b"WS_RELAX_LITE_FROM",
+                 b"WS_RELAX_EARLY_CAP", b"WS_RELAX_NO_SPLIT", b"WS_RELAX_NO_SEAM", b"WS_RELAX_LIST_FROM", b"WS_RELAX_SAME_GRID_FROM", b"WS_RELAX_LITE_FROM",
                  b"WS_DEBUG_LIST", b"WS_RELAX_NO_APPEND", b"WS_RELAX_SCAN_FROM", b"getenv"):
         assert knob not in blob, knob
     for src in ("ws_api.hip", "ws_kernels.hip", "ws_relax.hip", "ws_merge.hip", "ws_preproc.hip"):
