@@ -785,13 +785,18 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     const uint32_t qbit = 1u << ((band >= NB / 2 ? 2 : 0) + (xl >= LX / 2 ? 1 : 0));
     // (bits 6 .. 9: the same changes by SIDE -- top row, bottom row, left column, right column -- for the passes that
     // stay on one grid, where a side matters to exactly one neighbour)
+    // (SEAM 1: what a band changes in its first and last four columns, where a vertical seam runs, is the business of the
+    // strip that follows -- it looks at those columns again, in every row -- and raises no flag here: with them a band's
+    // first / last row "changed" in a quarter of the bands, whatever their height, for the two seam pixels at its corners;
+    // tools/sim_tile_schedule.c, SIM_REPAIR: 55 % of the tiles flagged with them, 41 % without, 9 % with bands of 16 rows)
+    const bool row_counts = SEAM != 1 || !((lane == 0 && x0 > 0) || (lane == 63 && x0 + TW < W));
     if (band == 0) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][xl * RX_P]);
-      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit | 64u;
+      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit | (row_counts ? 64u : 0u);
     }
     if (band == NB - 1) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][xl * RX_P]);
-      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit | 128u;
+      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit | (row_counts ? 128u : 0u);
     }
     if (SEAM == 2) {
       // a lane pair raises its own flags: the anchored tile that holds this lane's columns (left of the seam for the even
@@ -1092,8 +1097,19 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   // carrying a flood across its 256 columns sweep by sweep.
   constexpr uint32_t SEAM_REPAIR_ROUNDS = 4;
   if (seam_flow && pass == 1) {
-    k_relax<2, false, false, false, false, 1><<<ax * (ay - 1), 128, 0, s>>>(img, img_stride, keys, h, w, ax, ay - 1, sx, sy, 0, 1, max_level, pass, prev, cur,
-                                                                          pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0, 0, list_cap, 0);
+    // Rows each side of a seam (tuning knob, tools/ only).  What pass 0 leaves wrong thins out fourfold per pixel of distance from
+    // the seam, and a band raises a flag when its first or last row changes: with 4 rows a side 41 % of the tiles are flagged
+    // (pass 2: 52 us), with 6 a tile in eight (25 us), with 8 one in eleven (23 us) -- and the bands cost 35 / 50 / 59 us.
+    static const int seam_band = [] { const char *e = tuning_env("WS_RELAX_SEAM_BAND"); return e ? atoi(e) : 6; }();
+    if (seam_band == 4)
+      k_relax<2, false, false, false, false, 1><<<ax * (ay - 1), 128, 0, s>>>(img, img_stride, keys, h, w, ax, ay - 1, sx, sy, 0, 1, max_level, pass, prev, cur,
+                                                                            pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0, 0, list_cap, 0);
+    else if (seam_band == 6)
+      k_relax<3, false, false, false, false, 1><<<ax * (ay - 1), 192, 0, s>>>(img, img_stride, keys, h, w, ax, ay - 1, sx, sy, 0, 1, max_level, pass, prev, cur,
+                                                                            pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0, 0, list_cap, 0);
+    else
+      k_relax<4, false, false, false, false, 1><<<ax * (ay - 1), 256, 0, s>>>(img, img_stride, keys, h, w, ax, ay - 1, sx, sy, 0, 1, max_level, pass, prev, cur,
+                                                                            pf, SEAM_REPAIR_ROUNDS, nullptr, 0, sh, check_carry, pad, tile_list, 0, 0, 0, list_cap, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int strips_x = (ax - 1 + 31) / 32;
@@ -1104,10 +1120,12 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }
   const int sb = pass == 0 && seed_labels && seed_bits ? 1 : 0;
   const uint32_t *sl = pass == 0 ? seed_labels : nullptr;
-  if (pass < chunk_from && pass < lite_from) {
+  // (pass 2 after a seam repair runs a tile in ten: a workgroup per four tiles, as in the later passes)
+  const uint32_t chunk_from_now = seam_flow ? std::min(chunk_from, 2u) : chunk_from;
+  if (pass < chunk_from_now && pass < lite_from) {
     k_relax<RX_NW, false, false, false><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, seam_flow && pass == 0 ? 3 : 1, max_level, pass,
                                                                        prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
-  } else if (pass < chunk_from) {
+  } else if (pass < chunk_from_now) {
     k_relax<RX_NW, false, false, true><<<tx * ty, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, 1, max_level, pass,
                                                                       prev, cur, pf, max_iters, sl, sb, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
   } else {

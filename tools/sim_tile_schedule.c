@@ -28,6 +28,7 @@
 static uint32_t *key, *base, *snap;
 static int N;
 static long g_rounds, g_ops[128];
+static int g_skip_l, g_skip_r;      /* columns at the left / right end of a tile whose changes do not count as a changed first / last row */
 static uint32_t g_side_min[5]; /* smallest new key among the changed pixels of the top / bottom / left / right border, and of the tile */
 
 static inline uint32_t med3(uint32_t lo, uint32_t x, uint32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -159,8 +160,9 @@ static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe)
         key[p] = n;
         res |= 16;
         if (n < g_side_min[4]) g_side_min[4] = n;
-        if (y == 0) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
-        if (y == th - 1 || y0 + y == N - 1) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
+        const int row_counts = x >= g_skip_l && x < tw - g_skip_r;
+        if (y == 0 && row_counts) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
+        if ((y == th - 1 || y0 + y == N - 1) && row_counts) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
         if (x == 0) { res |= 4; if (n < g_side_min[2]) g_side_min[2] = n; }
         if (x == tw - 1 || x0 + x == N - 1) { res |= 8; if (n < g_side_min[3]) g_side_min[3] = n; }
       }
@@ -241,6 +243,78 @@ int main(int argc, char **argv) {
     runs += ran;
     waves += (ran + slots - 1) / slots;
     uint32_t *tt = pending; pending = pnext; pnext = tt;
+  }
+  if (getenv("SIM_REPAIR")) {
+    /* The seam repair of ws_relax.hip, replayed: pass 0 (every tile to its own fixpoint), then bands of +-kb rows along the
+     * horizontal seams (tiles tw wide), then strips of +-ks columns along the vertical seams (slices th tall), every launch
+     * with the halo as the launch found it; which regular tiles get flagged, and why.  SIM_REPAIR="kb,ks[,order]" with order
+     * 0 = bands then strips (the engine), 1 = strips then bands, 2 = bands, strips, then a second strip launch half a
+     * slice higher, 3 = as 2 plus a second band launch half a tile to the right. */
+    int kb = 4, ks = 4, order = 0;
+    sscanf(getenv("SIM_REPAIR"), "%d,%d,%d", &kb, &ks, &order);
+    uint32_t *truth = malloc(n * 4);
+    memcpy(truth, key, n * 4);
+    for (size_t p = 0; p < n; ++p) key[p] = KEY_INF;
+    for (size_t i = 0; i < ns; ++i) key[seeds[i]] = 0;
+    memcpy(snap, key, n * 4);
+    for (int j = 0; j < ty; ++j)
+      for (int i = 0; i < tx; ++i) run_tile(i * tw, j * th, tw, th, 0, recipe);
+    uint8_t *flag = calloc((size_t)tx * ty, 1);
+    long why[4] = {0, 0, 0, 0};      /* band rows, strip columns, strip slice rows, band columns (only when no strips follow) */
+    /* scratch tiles for other shapes */
+    free(cur); free(beg); free(bar); free(bs);
+    const size_t big = (size_t)(th + 2 * kb + 2 + 64) * (tw + 2 * ks + 2 + 64);
+    cur = malloc(big * 4); beg = malloc(big * 4); bar = malloc(big * 4); bs = malloc(big * 4);
+#define FLAG(i_, j_, w_) do { if ((i_) >= 0 && (i_) < tx && (j_) >= 0 && (j_) < ty) { if (!flag[(size_t)(j_) * tx + (i_)]) ++why[w_]; flag[(size_t)(j_) * tx + (i_)] = 1; } } while (0)
+    for (int phase = 0; phase < 4; ++phase) {
+      int what;      /* 0 bands, 1 strips, 2 strips shifted, 3 bands shifted, -1 nothing */
+      if (order == 0) what = phase == 0 ? 0 : (phase == 1 ? 1 : -1);
+      else if (order == 1) what = phase == 0 ? 1 : (phase == 1 ? 0 : -1);
+      else if (order == 2) what = phase == 0 ? 0 : (phase == 1 ? 1 : (phase == 2 ? 2 : -1));
+      else what = phase == 0 ? 0 : (phase == 1 ? 1 : (phase == 2 ? 2 : 3));
+      if (what < 0) continue;
+      const int last_bands = (order == 1);      /* no strips after the bands: their columns flag too */
+      memcpy(snap, key, n * 4);
+      if (what == 0 || what == 3) {
+        const int xoff = what == 3 ? tw / 2 : 0;
+        for (int j = 1; j < ty; ++j)
+          for (int i = 0; i * tw - xoff < N; ++i) {
+            const int x0 = i * tw - xoff;
+            /* what a band changes in the columns a strip will look at again is the strip's business */
+            if (getenv("SIM_REPAIR_SKIP") && !last_bands && what == 0) { g_skip_l = x0 > 0 ? ks : 0; g_skip_r = x0 + tw < N ? ks : 0; }
+            const int r = run_tile(x0 < 0 ? 0 : x0, j * th - kb, x0 < 0 ? tw + x0 : tw, 2 * kb, 0, recipe);
+            g_skip_l = g_skip_r = 0;
+            const int ti = (x0 < 0 ? 0 : x0) / tw;
+            if (r & 1) { FLAG(ti, j - 1, 0); if (xoff) FLAG(ti + 1, j - 1, 0); }
+            if (r & 2) { FLAG(ti, j, 0); if (xoff) FLAG(ti + 1, j, 0); }
+            if ((last_bands || what == 3) && (r & 4)) { FLAG((x0 - 1) / tw, j - 1, 3); FLAG((x0 - 1) / tw, j, 3); }
+            if ((last_bands || what == 3) && (r & 8)) { FLAG((x0 + tw) / tw, j - 1, 3); FLAG((x0 + tw) / tw, j, 3); }
+          }
+      } else {
+        const int yoff = what == 2 ? th / 2 : 0;
+        for (int i = 1; i < tx; ++i)
+          for (int j = 0; j * th - yoff < N; ++j) {
+            const int y0 = j * th - yoff;
+            const int r = run_tile(i * tw - ks, y0 < 0 ? 0 : y0, 2 * ks, y0 < 0 ? th + y0 : th, 0, recipe);
+            const int tj = (y0 < 0 ? 0 : y0) / th;
+            if (r & 4) { FLAG(i - 1, tj, 1); if (yoff) FLAG(i - 1, tj + 1, 1); }
+            if (r & 8) { FLAG(i, tj, 1); if (yoff) FLAG(i, tj + 1, 1); }
+            /* a slice's first / last row: covered by what follows? bands after strips cover the rows at the seams */
+            const int rows_covered = (order == 1 && what == 1) || (order >= 2 && what == 1);
+            if (!rows_covered && (r & 1)) { FLAG(i - 1, (y0 - 1) / th, 2); FLAG(i, (y0 - 1) / th, 2); }
+            if (!rows_covered && (r & 2)) { FLAG(i - 1, (y0 + th) / th, 2); FLAG(i, (y0 + th) / th, 2); }
+          }
+      }
+    }
+    long flagged = 0, wrong = 0, wrong_unflagged = 0;
+    for (size_t t = 0; t < (size_t)tx * ty; ++t) flagged += flag[t];
+    for (int y = 0; y < N; ++y)
+      for (int x = 0; x < N; ++x)
+        if (key[(size_t)y * N + x] != truth[(size_t)y * N + x]) { ++wrong; if (!flag[(size_t)(y / th) * tx + x / tw]) ++wrong_unflagged; }
+    printf("repair kb %d ks %d order %d: %ld of %d tiles flagged (%.1f %%): first flagged by band rows %ld, strip columns %ld, strip slice rows %ld, band columns %ld; "
+           "%ld stamps still wrong, %ld of them in tiles nobody flagged (those need a neighbour's flag: an equation next to them is violated)\n",
+           kb, ks, order, flagged, tx * ty, 100.0 * flagged / (tx * ty), why[0], why[1], why[2], why[3], wrong, wrong_unflagged);
+    memcpy(key, truth, n * 4);
   }
   if (getenv("SIM_SEAM_REPORT")) {
     /* key[] is the fixpoint now.  Replay pass 0 alone and report how far from the nearest tile seam the pixels are that it
