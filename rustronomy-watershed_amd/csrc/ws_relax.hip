@@ -790,20 +790,28 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     // first / last row "changed" in a quarter of the bands, whatever their height, for the two seam pixels at its corners;
     // tools/sim_tile_schedule.c, SIM_REPAIR: 55 % of the tiles flagged with them, 41 % without, 9 % with bands of 16 rows)
     const bool row_counts = SEAM != 1 || !((lane == 0 && x0 > 0) || (lane == 63 && x0 + TW < W));
+    // A changed border pixel only MATTERS to the tile across the border when it can lower the pixel it touches there:
+    // new stamp + 1 < that pixel's stamp -- which this tile holds, as its halo.  (The halo is as old as the tile's load: the
+    // pixel can only have fallen since, so the test errs on the side of flagging.)  On smooth maps a third to a half of the
+    // late tile runs changed nothing at all (tools/sim_tile_schedule.c, SIM_CHANGED): flagged by a neighbour whose front
+    // had not caught up with theirs.
+    auto matters = [](uint32_t before, uint32_t now, uint32_t across) { return before != now && now + 1u < across; };
     if (band == 0) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][xl * RX_P]);
-      if (o.x != T[0][0] || o.y != T[0][1] || o.z != T[0][2] || o.w != T[0][3]) e |= qbit | (row_counts ? 64u : 0u);
+      const u32x4_t a = *reinterpret_cast<const u32x4_t *>(&sRow[0][xl * RX_P]);      // the halo row above, as loaded
+      if (matters(o.x, T[0][0], a.x) || matters(o.y, T[0][1], a.y) || matters(o.z, T[0][2], a.z) || matters(o.w, T[0][3], a.w)) e |= qbit | (row_counts ? 64u : 0u);
     }
     if (band == NB - 1) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][xl * RX_P]);
-      if (o.x != T[3][0] || o.y != T[3][1] || o.z != T[3][2] || o.w != T[3][3]) e |= qbit | (row_counts ? 128u : 0u);
+      const u32x4_t a = *reinterpret_cast<const u32x4_t *>(&sRow[2 * NB + 1][xl * RX_P]);      // the halo row below
+      if (matters(o.x, T[3][0], a.x) || matters(o.y, T[3][1], a.y) || matters(o.z, T[3][2], a.z) || matters(o.w, T[3][3], a.w)) e |= qbit | (row_counts ? 128u : 0u);
     }
     if (SEAM == 2) {
       // a lane pair raises its own flags: the anchored tile that holds this lane's columns (left of the seam for the even
       // lane, right of it for the odd one), and that tile's neighbour above / below when the slice's first / last row changed
       bool col = false;
 #pragma unroll
-      for (int r = 0; r < RX_P; ++r) col |= init_col[r] != T[r][(lane & 1) ? 3 : 0];
+      for (int r = 0; r < RX_P; ++r) col |= matters(init_col[r], T[r][(lane & 1) ? 3 : 0], (lane & 1) ? Rh[r] : Lh[r]);      // (Lh / Rh of these lanes: the halo column)
       col |= unfinished;      // stopped at the round cap: the tiles on both sides of every seam of this slice look again
       const int fx = seam_x / SEAM_PX - 1 + (lane & 1);
       const uint32_t mark = pass + 1;
@@ -816,7 +824,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     } else if (xl == 0 || xl == LX - 1) {
 #pragma unroll
       for (int r = 0; r < RX_P; ++r)
-        if (sInitCol[xl == 0 ? 0 : 1][band * RX_P + r] != T[r][xl == 0 ? 0 : 3]) e |= qbit | (xl == 0 ? 256u : 512u);
+        if (matters(sInitCol[xl == 0 ? 0 : 1][band * RX_P + r], T[r][xl == 0 ? 0 : 3], xl == 0 ? Lh[r] : Rh[r])) e |= qbit | (xl == 0 ? 256u : 512u);      // (Lh of a row's first lane, Rh of its last: the halo column)
     }
   }
   // (SEAM 2, a slice that stopped at its round cap: also the lanes that changed nothing ask for their tile's re-run)

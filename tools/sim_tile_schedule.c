@@ -28,6 +28,8 @@
 static uint32_t *key, *base, *snap;
 static int N;
 static long g_rounds, g_ops[128];
+static long g_chg_hist[12], g_chg_runs, g_bbox_rows_hist[9], g_bbox_cols_hist[9];      /* SIM_CHANGED: changed pixels per tile run (log2 bins), height / width of their bounding box in eighths of the tile */
+static int g_matters;
 static int g_skip_l, g_skip_r;      /* columns at the left / right end of a tile whose changes do not count as a changed first / last row */
 static uint32_t g_side_min[5]; /* smallest new key among the changed pixels of the top / bottom / left / right border, and of the tile */
 
@@ -152,6 +154,15 @@ static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe)
     if (cap && round >= cap) { res |= 32; break; }
   }
   for (int k = 0; k < 5; ++k) g_side_min[k] = 0xFFFFFFFFu;
+  {
+    long nchg = 0; int ymin = th, ymax = -1, xmin = tw, xmax = -1;
+    for (int y = 0; y < th && y0 + y < N; ++y)
+      for (int x = 0; x < tw && x0 + x < N; ++x)
+        if (cur[(y + 1) * P + x + 1] != key[(size_t)(y0 + y) * N + x0 + x]) { ++nchg; if (y < ymin) ymin = y; if (y > ymax) ymax = y; if (x < xmin) xmin = x; if (x > xmax) xmax = x; }
+    int b = 0; while ((1L << b) <= nchg && b < 11) ++b;
+    ++g_chg_hist[b]; ++g_chg_runs;
+    if (nchg) { ++g_bbox_rows_hist[((ymax - ymin + 1) * 8 + th - 1) / th]; ++g_bbox_cols_hist[((xmax - xmin + 1) * 8 + tw - 1) / tw]; }
+  }
   for (int y = 0; y < th && y0 + y < N; ++y)
     for (int x = 0; x < tw && x0 + x < N; ++x) {
       const size_t p = (size_t)(y0 + y) * N + x0 + x;
@@ -161,10 +172,14 @@ static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe)
         res |= 16;
         if (n < g_side_min[4]) g_side_min[4] = n;
         const int row_counts = x >= g_skip_l && x < tw - g_skip_r;
-        if (y == 0 && row_counts) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
-        if ((y == th - 1 || y0 + y == N - 1) && row_counts) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
-        if (x == 0) { res |= 4; if (n < g_side_min[2]) g_side_min[2] = n; }
-        if (x == tw - 1 || x0 + x == N - 1) { res |= 8; if (n < g_side_min[3]) g_side_min[3] = n; }
+        /* SIM_MATTERS: a changed border pixel flags the tile across only if it can lower the pixel it touches there
+         * (new + 1 < that pixel's stamp as this tile loaded it: the halo ring of cur[]); =2: and that pixel is not at its base */
+        const int i2 = (y + 1) * P + x + 1;
+#define MATTERS(off) (!g_matters || (n + 1u < cur[i2 + (off)] && (g_matters < 2 || 1)))
+        if (y == 0 && row_counts && MATTERS(-P)) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
+        if ((y == th - 1 || y0 + y == N - 1) && row_counts && MATTERS(P)) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
+        if (x == 0 && MATTERS(-1)) { res |= 4; if (n < g_side_min[2]) g_side_min[2] = n; }
+        if ((x == tw - 1 || x0 + x == N - 1) && MATTERS(1)) { res |= 8; if (n < g_side_min[3]) g_side_min[3] = n; }
       }
     }
   return res;
@@ -211,6 +226,7 @@ int main(int argc, char **argv) {
   if (getenv("SIM_ADAPT")) sscanf(getenv("SIM_ADAPT"), "%ld,%ld", &adapt_lo, &adapt_hi);
   long passes = 0, runs = 0, waves = 0;
   const int verbose = getenv("SIM_VERBOSE") != NULL;
+  g_matters = getenv("SIM_MATTERS") ? atoi(getenv("SIM_MATTERS")) : 0;
   for (;;) {
     long ran = 0, waiting = 0;
     const long r0 = g_rounds;
@@ -235,6 +251,7 @@ int main(int argc, char **argv) {
         if ((r & 8) && i + 1 < tx) RAISE(t + 1, g_side_min[3]);
       }
     if (verbose) printf("  pass %ld: tiles %ld rounds %ld lowest %08x\n", passes, ran, g_rounds - r0, lowest);
+    if (getenv("SIM_CHANGED") && passes == atol(getenv("SIM_CHANGED"))) { memset(g_chg_hist, 0, sizeof g_chg_hist); memset(g_bbox_rows_hist, 0, sizeof g_bbox_rows_hist); memset(g_bbox_cols_hist, 0, sizeof g_bbox_cols_hist); g_chg_runs = 0; }
     if (adapt_hi && passes > 0) {
       if (ran < adapt_lo && waiting && delta < (1ull << 31)) delta *= 2;
       else if (ran > adapt_hi && delta > 16) delta /= 2;
@@ -343,6 +360,15 @@ int main(int argc, char **argv) {
     for (int d = 0; d < 64; ++d) { cum += hist[d]; if (hist[d]) printf(" %d:%ld", d, hist[d]); }
     printf("\n");
     memcpy(key, truth, n * 4);
+  }
+  if (getenv("SIM_CHANGED")) {
+    printf("tile runs after pass %s: %ld; changed pixels per run, bins 0, 1, 2-3, 4-7, ... >=1024:", getenv("SIM_CHANGED"), g_chg_runs);
+    for (int b = 0; b < 12; ++b) printf(" %ld", g_chg_hist[b]);
+    printf("\n  bounding box of the changes, rows in eighths of the tile height (1..8):");
+    for (int b = 1; b <= 8; ++b) printf(" %ld", g_bbox_rows_hist[b]);
+    printf("\n  columns in eighths of the tile width:");
+    for (int b = 1; b <= 8; ++b) printf(" %ld", g_bbox_cols_hist[b]);
+    printf("\n");
   }
   uint64_t sum = 0;
   for (size_t p = 0; p < n; ++p) sum += key[p] * (uint64_t)(p % 1000003 + 1);
