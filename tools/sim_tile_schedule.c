@@ -175,7 +175,10 @@ static int run_tile(int x0, int y0, int tw, int th, int cap, const char *recipe)
         /* SIM_MATTERS: a changed border pixel flags the tile across only if it can lower the pixel it touches there
          * (new + 1 < that pixel's stamp as this tile loaded it: the halo ring of cur[]); =2: and that pixel is not at its base */
         const int i2 = (y + 1) * P + x + 1;
-#define MATTERS(off) (!g_matters || (n + 1u < cur[i2 + (off)] && (g_matters < 2 || 1)))
+        /* (the pixel across, in the plane: its base says whether it can fall at all) */
+#define ACROSS_BASE(dx, dy) ((x0 + x + (dx) >= 0 && x0 + x + (dx) < N && y0 + y + (dy) >= 0 && y0 + y + (dy) < N) ? base[(size_t)(y0 + y + (dy)) * N + x0 + x + (dx)] : KEY_INF)
+#define MATTERS2(off, dx, dy) (!g_matters || (n + 1u < cur[i2 + (off)] && (g_matters < 2 || (cur[i2 + (off)] > ACROSS_BASE(dx, dy) && n + 1u < cur[i2 + (off)]))))
+#define MATTERS(off) MATTERS2(off, (off) == -1 ? -1 : ((off) == 1 ? 1 : 0), (off) == -P ? -1 : ((off) == P ? 1 : 0))
         if (y == 0 && row_counts && MATTERS(-P)) { res |= 1; if (n < g_side_min[0]) g_side_min[0] = n; }
         if ((y == th - 1 || y0 + y == N - 1) && row_counts && MATTERS(P)) { res |= 2; if (n < g_side_min[1]) g_side_min[1] = n; }
         if (x == 0 && MATTERS(-1)) { res |= 4; if (n < g_side_min[2]) g_side_min[2] = n; }
