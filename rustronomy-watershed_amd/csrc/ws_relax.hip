@@ -978,7 +978,11 @@ size_t relax_list_words(int h, int w) { return RL_HDR + 3 * relax_tiles(h, w) + 
 
 // capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column; the 128 x 64 grid of the
 // same-grid passes has its own count
-constexpr int RX_STW = RX_TW / 2, RX_STH = 2 * RX_NW * RX_P;      // tile of the SPLIT kernel: 128 x 64
+#ifndef WS_SPLIT_NW
+#define WS_SPLIT_NW RX_NW
+#endif
+constexpr int RX_SNW = WS_SPLIT_NW;
+constexpr int RX_STW = RX_TW / 2, RX_STH = 2 * RX_SNW * RX_P;      // tile of the SPLIT kernel: 128 x 64
 size_t relax_tiles(int h, int w) {
   const int th = RX_NW * RX_P;
   const size_t a = (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
@@ -1171,7 +1175,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         if (e != hipSuccess) return e;
       }
       if (split)
-        k_relax<RX_NW, true, true, true, true><<<std::min<unsigned>(RX_LIST_GRID, (unsigned)(gx * gy)), 64 * RX_NW, 0, s>>>(
+        k_relax<RX_SNW, true, true, true, true><<<std::min<unsigned>(RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy)), 64 * RX_SNW, 0, s>>>(
             img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
             check_carry, pad, tile_list, 1, 1, 1, list_cap, append_next);
       else
