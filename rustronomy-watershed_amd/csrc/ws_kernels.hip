@@ -186,6 +186,45 @@ __device__ __forceinline__ size_t seed_lower_bound(const uint2 *__restrict__ see
   return lo;
 }
 
+// Two lower bounds (pa <= pb) in one walk: the probes of both searches are in flight together, so a wave that needs both
+// ends of its chunk pays the dependent round trips of one search (k_seed_tables is little else: 8 of its ~12).
+__device__ __forceinline__ void seed_lower_bound2(const uint2 *__restrict__ seeds, size_t n, int pw, unsigned long long pa,
+                                                  unsigned long long pb, int lane, size_t &out_a, size_t &out_b) {
+  if (n == 0) { out_a = out_b = 0; return; }      // (no list to probe)
+  size_t lo[2] = {0, 0}, hi[2] = {n, n};
+  const unsigned long long p[2] = {pa, pb};
+  while (hi[0] - lo[0] > 64 || hi[1] - lo[1] > 64) {
+    size_t step[2], j[2];
+    uint2 probe[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      step[k] = (hi[k] - lo[k] + 63) / 64;
+      j[k] = lo[k] + (size_t)lane * step[k];
+      probe[k] = seeds[j[k] < hi[k] ? j[k] : n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (hi[k] - lo[k] <= 64) continue;      // uniform
+      const bool before = j[k] < hi[k] && seed_pos(probe[k], pw) < p[k];
+      const int c = __popcll(__builtin_amdgcn_ballot_w64(before));
+      if (c == 0) { hi[k] = lo[k]; continue; }
+      const size_t nlo = lo[k] + (size_t)(c - 1) * step[k] + 1, nhi = lo[k] + (size_t)c * step[k];
+      hi[k] = nhi < hi[k] ? nhi : hi[k];
+      lo[k] = nlo;
+    }
+  }
+  uint2 last[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) last[k] = seeds[lo[k] + lane < hi[k] ? lo[k] + lane : n - 1];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool before = hi[k] > lo[k] && lo[k] + lane < hi[k] && seed_pos(last[k], pw) < p[k];
+    lo[k] += __popcll(__builtin_amdgcn_ballot_w64(before));
+  }
+  out_a = lo[0];
+  out_b = lo[1];
+}
+
 __global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
                                                                   uint32_t *labels, size_t npx, size_t nchunk, int steps,
                                                                   uint32_t *err_flag,
@@ -262,6 +301,7 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_paint_sorted(const uint32_
 // the word popcounts gives the bases.  Nothing here repairs a list that is not strictly increasing:
 // flags[2] tells the caller, who repeats the transform with paint_labels.
 constexpr int TAB_WORDS = 256;       // mask words per wave (8192 pixels): four per lane
+constexpr int TAB_WIN = 4;           // windows of 64 list entries in flight per round of the walk
 
 __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t *__restrict__ seeds_rc, size_t n, int ph, int pw,
                                                                  uint32_t *mask, uint32_t *word_base, size_t npx, size_t nchunk,
@@ -289,24 +329,27 @@ __global__ __launch_bounds__(64 * PAINT_WAVES) void k_seed_tables(const uint32_t
   // if every range passes, the whole list is strictly increasing.  Anything else raises flags[2] (and flags[0] for a
   // seed outside the plane) and the caller repeats the transform with paint_labels, whose own checks name the fault.
   // (A separate pass over the list for these checks was 58 of the kernel's 161 MB.)
-  const size_t lo = seed_lower_bound(seeds, n, pw, p0, lane);
-  size_t hi = chunk + 1 == nchunk ? n : seed_lower_bound(seeds, n, pw, p1, lane);
+  size_t lo, hi;
+  seed_lower_bound2(seeds, n, pw, p0, p1, lane, lo, hi);
+  if (chunk + 1 == nchunk) hi = n;
   bool bad = hi < lo || hi - lo > (size_t)TAB_WORDS * 32;      // more seeds than pixels: not worth walking
   if (bad) hi = lo;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the zeroed row before the bits
 
-  // four windows of 64 seeds per round, all four loads in flight together
+  // TAB_WIN windows of 64 seeds per round, all their loads in flight together (sixteen windows a round -- a chunk of the
+  // bench field holds ~890 seeds -- changed nothing: of the kernel's 30 us the two searches are 9, the rest is the list
+  // streaming through; profiles/r2_v7_chase_ab.log)
   unsigned long long prev_last = 0;      // position of the seed before the round's first (none: the first of the range)
   bool have_prev = false;
-  for (size_t wbase = lo; wbase < hi; wbase += 256) {
-    uint2 win[4];
+  for (size_t wbase = lo; wbase < hi; wbase += 64 * TAB_WIN) {
+    uint2 win[TAB_WIN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < TAB_WIN; ++k) {
       const size_t j = wbase + 64 * k + lane;
       win[k] = seeds[j < hi ? j : hi - 1];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < TAB_WIN; ++k) {
       const size_t j = wbase + 64 * k + lane;
       const unsigned long long pos = seed_pos(win[k], pw);
       const bool mine = j < hi;
@@ -787,7 +830,8 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
     const int side = tid >> 6, t = tid & 63;
     const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
     const int hx = side == 2 ? x0 - 1 : (side == 3 ? x0 + TS : x0 + t);
-    const uint32_t hv = keys[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
+    const size_t hg = (size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1);
+    const uint32_t hv = keys[hg];
     const bool hok = hy >= 0 && hy < H && hx >= 0 && hx < W;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -939,6 +983,9 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
     const int hy = side == 0 ? y0 - 1 : (side == 1 ? y0 + TS : y0 + t);
     const int hx = side == 2 ? x0 - 1 : (side == 3 ? x0 + TS : x0 + t);
     const int hyc = min(max(hy, 0), H - 1), hxc = min(max(hx, 0), W - 1);
+    // (tried: a halo cell that is a SEED holds the seed's colour, from the side tables, instead of a reference -- half of the
+    // leaving chains of a random field end there: k_resolve_chase 41 -> 27 us, and this kernel 170 -> 183 us for the two
+    // table words per halo cell, the left and right columns' a cache line each)
     sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = REF_BIT | (uint32_t)((size_t)hyc * W + hxc);
   }
 #pragma unroll
@@ -1031,10 +1078,17 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   WS_STAMP(5);
 }
 
-// One wave per list region (grid-stride).  A reference always points to a pixel with a strictly
+// A wave per CH_R consecutive list regions (grid-stride).  A reference always points to a pixel with a strictly
 // smaller stamp, so chains end at a seed; a racing reader sees either the reference or what it
 // resolves to.
-__global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
+// On the bench field a region holds ~20 references and nearly every chain is one hop long: the kernel is three dependent
+// memory round trips (count, entry, target) per wave and nothing else, so a wave takes the counts of CH_R regions in one
+// load, walks their entries as ONE flattened list, CH_U entries per lane in flight, and issues the first hop of all of
+// them before it waits (one region at a time, four per wave one after the other: 48 us at 8192^2, 75 MB of traffic; this
+// form 41 us, whatever CH_R and CH_U: reading the lists is 6 us of it, the scattered 4-byte loads of the first hop ~10-17 and
+// the scattered 4-byte stores ~18-28 -- partial writes into lines k_resolve_local has just sent to HBM; profiles/r2_v7_chase_ab.log).
+constexpr int CH_R = 8, CH_U = 4;
+__global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
                                 const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err,
                                 size_t follow_from, size_t follow_to) {
@@ -1044,18 +1098,55 @@ __global__ void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ r
   if (seed_err && (seed_err[0] | seed_err[2]) != 0u) return;      // invalid side tables: k_resolve_local wrote no lists (see there)
   if (gate && __builtin_amdgcn_ballot_w64(gate[lane * STRIPE_STRIDE] != 0u) != 0ull) return;      // see k_resolve_local
   const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-  for (size_t region = wave0; region < nregions; region += nwaves) {
-    const uint32_t count = ref_count[region];
-    const uint2 *list = reinterpret_cast<const uint2 *>(ref_list) + region * REF_REGION;
-    for (uint32_t j = lane; j < count; j += 64) {
-      const uint2 e = list[j];
-      uint32_t v = e.y | REF_BIT;
+  const size_t ngroups = (nregions + CH_R - 1) / CH_R;
+  const size_t span = follow_to - follow_from;
+  for (size_t grp = wave0; grp < ngroups; grp += nwaves) {
+    const size_t r0 = grp * CH_R;
+    uint32_t cnt = 0;
+    if (lane < CH_R && r0 + lane < nregions) cnt = min(ref_count[r0 + lane], (uint32_t)REF_REGION);
+    const uint32_t incl = wave_inclusive_sum(cnt);      // lanes >= CH_R: the total
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t ends[CH_R - 1];                             // uniform: where region i + 1 starts in the flattened list
+#pragma unroll
+    for (int i = 0; i < CH_R - 1; ++i) ends[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
+    for (uint32_t jb = 0; jb < tot; jb += 64 * CH_U) {
+      uint2 e[CH_U];
+      uint32_t v[CH_U];
+      bool ok[CH_U];
+#pragma unroll
+      for (int u = 0; u < CH_U; ++u) {
+        const uint32_t j = jb + u * 64 + lane;
+        ok[u] = j < tot;
+        uint32_t reg = 0, base = 0;
+#pragma unroll
+        for (int i = 0; i < CH_R - 1; ++i)
+          if (j >= ends[i]) { reg = i + 1; base = ends[i]; }
+        // (a lane past the end reads entry 0 of the group's first region: inside the list, ignored)
+        e[u] = reinterpret_cast<const uint2 *>(ref_list)[(r0 + (ok[u] ? reg : 0u)) * REF_REGION + (ok[u] ? j - base : 0u)];
+      }
       // A reference points at a pixel with a strictly smaller stamp, so a chain visits a pixel at most once: fewer than n
       // hops.  The range test and the hop bound are belt and braces: with invalid side tables (the only source of words
       // that are not colours or references of this plane) both resolve kernels have already left.
-      for (size_t hops = 0; (v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < follow_to - follow_from && hops < n; ++hops)
-        v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      labels[e.x] = v;
+      // first hop of every entry: unconditional loads (pixel 0 for a lane with nothing to follow), one wait
+      bool follow[CH_U];
+      uint32_t first[CH_U];
+#pragma unroll
+      for (int u = 0; u < CH_U; ++u) {
+        v[u] = e[u].y | REF_BIT;
+        follow[u] = ok[u] && n != 0 && (size_t)e[u].y - follow_from < span;
+        first[u] = __hip_atomic_load(labels + (follow[u] ? e[u].y : (uint32_t)follow_from), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < CH_U; ++u) {
+        if (follow[u]) {
+          v[u] = first[u];
+          for (size_t hops = 1; (v[u] & REF_BIT) && (size_t)(v[u] & ~REF_BIT) - follow_from < span && hops < n; ++hops)
+            v[u] = __hip_atomic_load(labels + (v[u] & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CH_U; ++u)
+        if (ok[u]) labels[e[u].x] = v[u];
     }
   }
 }
@@ -1087,7 +1178,7 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
     k_resolve_local<false, false, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag, nullptr, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
+  const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
   const size_t from = (halo_flags & 1) ? (size_t)w : 0, to = (halo_flags & 2) ? n - (size_t)w : n;
   k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to);
   return hipGetLastError();
@@ -1099,7 +1190,7 @@ hipError_t resolve_chase_again(hipStream_t s, uint32_t *labels, int h, int w, ui
   const size_t n = (size_t)h * w;
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
-  const unsigned grid = (unsigned)std::min<size_t>((nregions + 3) / 4, 4096);
+  const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
   k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n);
   return hipGetLastError();
 }
