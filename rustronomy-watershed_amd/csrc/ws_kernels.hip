@@ -1101,7 +1101,8 @@ __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const u
   const size_t ngroups = (nregions + CH_R - 1) / CH_R;
   const size_t span = follow_to - follow_from;
   for (size_t grp = wave0; grp < ngroups; grp += nwaves) {
-    const size_t r0 = grp * CH_R;
+    // (last region first: the labels k_resolve_local wrote last are the ones still in the memory-side cache -- 43 -> 38 us)
+    const size_t r0 = (ngroups - 1 - grp) * CH_R;
     uint32_t cnt = 0;
     if (lane < CH_R && r0 + lane < nregions) cnt = min(ref_count[r0 + lane], (uint32_t)REF_REGION);
     const uint32_t incl = wave_inclusive_sum(cnt);      // lanes >= CH_R: the total
