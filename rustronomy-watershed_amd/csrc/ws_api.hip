@@ -1579,7 +1579,7 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
     HIP_TRY(c, union_image(c->stream, seg, seeds, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
                            c->tile_min_filled));
-    HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n, (const uint32_t *)c->counts.p, (int)ph, (int)pw));
+    HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n, (uint32_t *)c->counts.p, (int)ph, (int)pw));
   }
   c->stats.merge_levels = 1;
   return stats_end(c);

@@ -31,6 +31,16 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
   }
 }
 
+// root of x by a plain walk: no halving, no atomics (for a forest nobody is changing during the launch, or a crowd of
+// readers of the same few chains, whose halving atomics would queue up on the same words)
+__device__ __forceinline__ uint32_t uf_root(const uint32_t *parent, uint32_t x) {
+  for (;;) {
+    const uint32_t p = ld_parent(parent, x);
+    if (p == x) return x;
+    x = p;
+  }
+}
+
 // returns the node that lost its root status (hooked under a smaller root), or 0xFFFFFFFF
 __device__ __forceinline__ uint32_t uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
   for (;;) {
@@ -646,24 +656,49 @@ __global__ __launch_bounds__(256) void k_tile_scan(const uint32_t *__restrict__ 
   if (tid == 0) tile_min[blockIdx.x] = one_lake ? min(min(sWaveMin[0], sWaveMin[1]), min(sWaveMin[2], sWaveMin[3])) + 1u : 0u;
 }
 
+// Every pair of one-lake tiles that share an edge must end in one set.  One union per pair (32 k of them at 8192^2, nearly
+// all into the same set) was 43 us of CAS retries on a few hot roots.  Instead: along a row, a RUN of one-lake tiles is
+// tied together by a segmented min-scan in the wave -- tile i joins the smallest colour of the run's tiles before it, a
+// child slot of its own and a chain a few hooks deep (the prefix minima of the run) -- and two runs in consecutive rows
+// are joined once, at the leftmost column they share (the head of one of them).
 __global__ void k_tile_links(const uint32_t *__restrict__ tile_min, int tilesX, int tilesY, uint32_t *parent) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= tilesX * tilesY) return;
-  const uint32_t m = tile_min[t];
+  const int lane = threadIdx.x & 63;
+  const bool in = t < tilesX * tilesY;
+  const int tx = in ? t % tilesX : 0, ty = in ? t / tilesX : 0;
+  const uint32_t m = in ? tile_min[t] : 0u;
+  const uint32_t left = in && tx > 0 ? tile_min[t - 1] : 0u;
+  const uint32_t md = in && ty + 1 < tilesY ? tile_min[t + tilesX] : 0u;
+  const uint32_t md_left = in && ty + 1 < tilesY && tx > 0 ? tile_min[t + tilesX - 1] : 0u;
+  const bool head = m != 0u && left == 0u, md_head = md != 0u && md_left == 0u;
+  // inclusive min over the run, from its first tile IN THIS WAVE to this lane (a tile that is not one lake is a segment
+  // of its own: its value is never used)
+  uint32_t v = m != 0u ? m : 0xFFFFFFFFu;
+  bool f = head || m == 0u || lane == 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t pv = (uint32_t)__shfl_up((int)v, d, 64);
+    const int pf = __shfl_up((int)f, d, 64);
+    if (lane >= d && !f) { v = min(v, pv); f = pf != 0; }
+  }
+  const uint32_t before = (uint32_t)__shfl_up((int)v, 1, 64);      // the run's smallest colour up to the tile on the left
   if (m == 0u) return;
-  const int tx = t % tilesX, ty = t / tilesX;
-  const uint32_t mr = tx + 1 < tilesX ? tile_min[t + 1] : 0u, md = ty + 1 < tilesY ? tile_min[t + tilesX] : 0u;
-  if (mr != 0u && mr != m) uf_union(parent, m, mr);
-  if (md != 0u && md != m) uf_union(parent, m, md);
+  if (!head) {
+    const uint32_t join = lane == 0 ? left : before;               // (lane 0: the run goes on from the wave before)
+    if (join != m) uf_union(parent, m, join);
+  }
+  if (md != 0u && md != m && (head || md_head)) uf_union(parent, m, md);
 }
 
 // after the links: every one-lake tile remembers the ROOT of its lake instead of its own smallest colour, so
 // that the 450 seeds of a tile find a root in one load instead of all walking (and compressing) the same chain
+// (a plain walk: the forest is at rest between two launches, and 16 k halving finds on the links' few chains were 29 us
+// of atomics on the same words against 6 us for the walk)
 __global__ void k_tile_roots(uint32_t *tile_min, int ntiles, uint32_t *parent) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntiles) return;
   const uint32_t m = tile_min[t];
-  if (m != 0u) tile_min[t] = uf_find(parent, m);
+  if (m != 0u && m != 0xFFFFFFFFu) tile_min[t] = uf_root(parent, m);
 }
 
 __global__ void k_union_seeds(const uint32_t *__restrict__ seeds_rc, size_t n_seeds, int H, int W, int tilesX,
@@ -764,7 +799,7 @@ __global__ void k_relabel_flat(const uint32_t *__restrict__ labels, const uint32
 
 // The same tile by tile, for a plane whose 64 x 64 tiles union_image has classified: a one-lake tile strictly inside the
 // image (every pixel coloured, all of one lake: tile_min = a colour of it) is FILLED with its root -- no label is read;
-// every other tile takes the gather.  At the final level of a map that floods completely nearly every tile is one lake:
+// every other tile takes the gather (of roots: uf_root).  At the final level of a map that floods completely nearly every tile is one lake:
 // 8192^2 bench field 121 -> ~60 us (the gather reads and writes the plane, 537 MB; the fill writes 268 MB).
 __global__ __launch_bounds__(256) void k_relabel_tiles(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ parent,
                                                        const uint32_t *__restrict__ tile_min, uint32_t *out, int H, int W, int tilesX) {
@@ -775,7 +810,7 @@ __global__ __launch_bounds__(256) void k_relabel_tiles(const uint32_t *__restric
   const bool inside = x0 >= 1 && x0 + UT <= W - 1 && y0 >= 1 && y0 + UT <= H - 1;      // workgroup uniform
   const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
   if (cm != 0u && cm != 0xFFFFFFFFu && inside && vec) {
-    const uint32_t r = parent[cm];
+    const uint32_t r = cm;      // (a root: relabel_final_u32 runs k_tile_roots first)
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4_m *>(out + (size_t)(gy0 + k) * W + gx0) = u32x4_m{r, r, r, r};
     return;
@@ -786,26 +821,32 @@ __global__ __launch_bounds__(256) void k_relabel_tiles(const uint32_t *__restric
     if (gy >= H) break;
     if (vec && gx0 + 4 <= W) {
       const u32x4_m l = *reinterpret_cast<const u32x4_m *>(labels + (size_t)gy * W + gx0);
-      *reinterpret_cast<u32x4_m *>(out + (size_t)gy * W + gx0) = u32x4_m{parent[l.x], parent[l.y], parent[l.z], parent[l.w]};
+      *reinterpret_cast<u32x4_m *>(out + (size_t)gy * W + gx0) = u32x4_m{uf_root(parent, l.x), uf_root(parent, l.y), uf_root(parent, l.z), uf_root(parent, l.w)};
     } else {
       for (int c = 0; c < 4; ++c)
-        if (gx0 + c < W) out[(size_t)gy * W + gx0 + c] = parent[labels[(size_t)gy * W + gx0 + c]];
+        if (gx0 + c < W) out[(size_t)gy * W + gx0 + c] = uf_root(parent, labels[(size_t)gy * W + gx0 + c]);
     }
   }
 }
 
 hipError_t relabel_final_u32(hipStream_t s, const uint32_t *labels, uint32_t *parent, size_t n_colours, uint32_t *out, size_t n,
-                             const uint32_t *tile_min, int h, int w) {
+                             uint32_t *tile_min, int h, int w) {
   if (n == 0) return hipSuccess;
+  if (tile_min && (size_t)h * w == n) {
+    // (no flattening pass over the 7 M colours first -- k_uf_flatten was 21 us at 8192^2: a one-lake tile needs ONE root,
+    // found once per tile by k_tile_roots -- the seeds' unions hook the lake's root under ever smaller colours, a chain
+    // ~ln(n) hooks deep that every tile would otherwise walk -- and the other tiles walk what path halving left)
+    const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
+    k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return e0;
+    k_relabel_tiles<<<tx * ty, 256, 0, s>>>(labels, parent, tile_min, out, h, w, tx);
+    return hipGetLastError();
+  }
   const int fb = (int)std::min<size_t>((n_colours + 255) / 256, 8192);
   k_uf_flatten<<<fb > 0 ? fb : 1, 256, 0, s>>>(parent, n_colours);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (tile_min && (size_t)h * w == n) {
-    const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
-    k_relabel_tiles<<<tx * ty, 256, 0, s>>>(labels, parent, tile_min, out, h, w, tx);
-    return hipGetLastError();
-  }
   const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 16384);
   k_relabel_flat<<<blocks, 256, 0, s>>>(labels, parent, out, n);
   return hipGetLastError();

@@ -72,7 +72,7 @@ hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *se
                        uint32_t *parent, uint32_t *tile_min, bool preclassified = false);      // preclassified: resolve_two_launch filled tile_min
 // flattens the forest (n_colours entries, entry 0 = "uncoloured" points at itself) and gathers out[i] = root(labels[i])
 hipError_t relabel_final_u32(hipStream_t s, const uint32_t *labels, uint32_t *parent, size_t n_colours, uint32_t *out, size_t n,
-                             const uint32_t *tile_min = nullptr, int h = 0, int w = 0);      // tile_min: union_image's classification of the h x w plane's tiles (one-lake tiles are filled)
+                             uint32_t *tile_min = nullptr, int h = 0, int w = 0);      // tile_min: union_image's classification of the h x w plane's tiles (one-lake tiles are filled)
 // out[p] = coloured by `level` ? root(labels[p]) : 0
 hipError_t relabel_u32(hipStream_t s, const uint32_t *keys, const uint32_t *labels, uint32_t *parent,
                        uint32_t *out, size_t n, uint32_t level);
