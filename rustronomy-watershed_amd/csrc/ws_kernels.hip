@@ -1087,7 +1087,9 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 // them before it waits (one region at a time, four per wave one after the other: 48 us at 8192^2, 75 MB of traffic; this
 // form 41 us, whatever CH_R and CH_U: reading the lists is 6 us of it, the scattered 4-byte loads of the first hop ~10-17 and
 // the scattered 4-byte stores ~18-28 -- partial writes into lines k_resolve_local has just sent to HBM; profiles/r2_v7_chase_ab.log).
-constexpr int CH_R = 8, CH_U = 4;
+// (groups of 8 regions balance badly on smooth maps, where every pixel is a reference and a region holds 1024: 8192^2 at
+// correlation 64 / 256 px 344 / 212 us against 301 / 144 with 4 and 269 / 259 for the old one-region walk; bench field 38 us either way)
+constexpr int CH_R = 4, CH_U = 4;
 __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
                                 const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err,
