@@ -740,6 +740,11 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
 
 constexpr uint32_t REF_BIT = 0x80000000u;
 constexpr size_t REF_REGION = 64 * 16;          // work-list entries per wave of k_resolve_local: its pixels
+constexpr uint32_t REF_ALL = 0xFFFFFFFFu;       // count word of a wave with REF_DENSE references or more: no list (see k_resolve_local)
+#ifndef WS_REF_DENSE
+#define WS_REF_DENSE 256
+#endif
+constexpr uint32_t REF_DENSE = WS_REF_DENSE;
 
 typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
 
@@ -1067,8 +1072,13 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   const uint32_t cnt = __popc(refmask);
   const uint32_t incl = wave_inclusive_sum(cnt);
   const size_t region = (size_t)blockIdx.x * (NTHREADS / 64) + wave;
-  if (lane == 63) ref_count[region] = incl;
-  if (refmask) {
+  // A quarter or more of the wave's pixels references (a smooth map: all of them, in a tile without a seed): no list --
+  // k_resolve_chase reads the wave's 64 x 16 pixels from the label plane itself, 16 bytes a lane and row, instead of 8
+  // bytes of list per reference written here and read there, and stores whole rows instead of single words (at 8192^2 and
+  // a correlation length of 64 px the lists were 1 GB of a transform's traffic: resolve 1.05 -> 0.44 ms).
+  const bool all_refs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >= REF_DENSE;      // wave uniform
+  if (lane == 63) ref_count[region] = all_refs ? REF_ALL : incl;
+  if (refmask && !all_refs) {
     // (pixel, what it refers to): the chase starts at the target without reading the pixel's own label first
     uint2 *dst = reinterpret_cast<uint2 *>(ref_list) + region * REF_REGION + (incl - cnt);
 #pragma unroll
@@ -1093,7 +1103,7 @@ constexpr int CH_R = 4, CH_U = 4;
 __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
                                 const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err,
-                                size_t follow_from, size_t follow_to) {
+                                size_t follow_from, size_t follow_to, int H, int W, int tilesX, uint32_t ntiles) {
   // [follow_from, follow_to): the pixels a chain may be followed THROUGH -- the whole plane [0, n), or, for a row block
   // whose halo rows still hold references to themselves, the plane without those rows: a chain stops at a halo pixel.
   const int lane = threadIdx.x & 63;
@@ -1106,7 +1116,9 @@ __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const u
     // (last region first: the labels k_resolve_local wrote last are the ones still in the memory-side cache -- 43 -> 38 us)
     const size_t r0 = (ngroups - 1 - grp) * CH_R;
     uint32_t cnt = 0;
-    if (lane < CH_R && r0 + lane < nregions) cnt = min(ref_count[r0 + lane], (uint32_t)REF_REGION);
+    if (lane < CH_R && r0 + lane < nregions) cnt = ref_count[r0 + lane];
+    const unsigned long long all_refs = __builtin_amdgcn_ballot_w64(cnt == REF_ALL);      // regions without a list (k_resolve_local)
+    cnt = cnt == REF_ALL ? 0u : min(cnt, (uint32_t)REF_REGION);
     const uint32_t incl = wave_inclusive_sum(cnt);      // lanes >= CH_R: the total
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint32_t ends[CH_R - 1];                             // uniform: where region i + 1 starts in the flattened list
@@ -1151,6 +1163,72 @@ __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const u
       for (int u = 0; u < CH_U; ++u)
         if (ok[u]) labels[e[u].x] = v[u];
     }
+    // the regions without a list: the wave of k_resolve_local that owned region r held the 4 x 4 patches (lane & 15,
+    // 4 (r & 3) + lane / 16) of tile xcd_span_index(r / 4); a label that is no reference is left alone
+    for (unsigned long long m = all_refs; m != 0ull; m &= m - 1ull) {
+      const size_t region = r0 + (size_t)__builtin_ctzll(m);
+      const uint32_t tile = xcd_span_index((uint32_t)(region / (NTHREADS / 64)), ntiles);
+      const int gx0 = (int)(tile % (uint32_t)tilesX) * TS + (lane & 15) * 4;
+      const int gy0 = (int)(tile / (uint32_t)tilesX) * TS + ((int)(region % (NTHREADS / 64)) * 4 + (lane >> 4)) * 4;
+      const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(labels) & 15u) == 0;
+      // (pixels outside the plane -- a tile at its right or lower edge -- read as label 0: no reference, never stored)
+      uint32_t L[4][4];
+      if (vec) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u32x4_r q = u32x4_r{0u, 0u, 0u, 0u};
+          if (gy0 + r < H && gx0 < W) q = *reinterpret_cast<const u32x4_r *>(labels + (size_t)(gy0 + r) * W + gx0);
+          L[r][0] = q.x; L[r][1] = q.y; L[r][2] = q.z; L[r][3] = q.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) L[r][c] = gy0 + r < H && gx0 + c < W ? labels[(size_t)(gy0 + r) * W + gx0 + c] : 0u;
+      }
+      // first hops: sixteen unconditional loads, one wait; neighbouring pixels mostly leave the tile by the same halo pixel
+      uint32_t first[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t t = L[r][c] & ~REF_BIT;
+          const bool go = (L[r][c] & REF_BIT) && n != 0 && (size_t)t - follow_from < span;
+          first[r][c] = __hip_atomic_load(labels + (go ? t : (uint32_t)follow_from), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      // ... and the rest of a chain once per run of pixels that share it (the hop bound as above)
+      uint32_t memo_from = 0u, memo_to = 0u;      // (0 is not a reference: never matches)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t t = L[r][c] & ~REF_BIT;
+          if ((L[r][c] & REF_BIT) && n != 0 && (size_t)t - follow_from < span) {
+            uint32_t v = first[r][c];
+            if ((v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < span) {
+              if (v == memo_from) v = memo_to;
+              else {
+                const uint32_t from = v;
+                for (size_t hops = 1; (v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < span && hops < n; ++hops)
+                  v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                memo_from = from; memo_to = v;
+              }
+            }
+            L[r][c] = v;
+          }
+        }
+      if (vec) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gy0 + r < H && gx0 < W) *reinterpret_cast<u32x4_r *>(labels + (size_t)(gy0 + r) * W + gx0) = u32x4_r{L[r][0], L[r][1], L[r][2], L[r][3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (gy0 + r < H && gx0 + c < W) labels[(size_t)(gy0 + r) * W + gx0 + c] = L[r][c];
+      }
+    }
   }
 }
 
@@ -1183,7 +1261,7 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
   const size_t from = (halo_flags & 1) ? (size_t)w : 0, to = (halo_flags & 2) ? n - (size_t)w : n;
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to, h, w, tx, (uint32_t)(tx * ty));
   return hipGetLastError();
 }
 
@@ -1194,7 +1272,7 @@ hipError_t resolve_chase_again(hipStream_t s, uint32_t *labels, int h, int w, ui
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
   const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n, h, w, tiles_of(w), (uint32_t)(tiles_of(w) * tiles_of(h)));
   return hipGetLastError();
 }
 
