@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   // a correlation length of 64 px the lists were 1 GB of a transform's traffic: resolve 1.05 -> 0.44 ms).
   const bool all_refs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >= REF_DENSE;      // wave uniform
   if (lane == 63) ref_count[region] = all_refs ? REF_ALL : incl;
-  if (refmask && !all_refs) {
+  if (refmask && !all_refs) {      // (the list writes are 8 of this kernel's 165 us on the bench field)
     // (pixel, what it refers to): the chase starts at the target without reading the pixel's own label first
     uint2 *dst = reinterpret_cast<uint2 *>(ref_list) + region * REF_REGION + (incl - cnt);
 #pragma unroll
