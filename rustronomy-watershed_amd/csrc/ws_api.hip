@@ -1578,7 +1578,7 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
     Span sp(c, KC_OTHER);
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
     HIP_TRY(c, union_image(c->stream, seg, seeds, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
-                           c->tile_min_filled));
+                           c->tile_min_filled, (uint32_t *)c->uf_size.p));      // (uf_init has just zeroed uf_size: the tile-root marks)
     HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n, (uint32_t *)c->counts.p, (int)ph, (int)pw));
   }
   c->stats.merge_levels = 1;

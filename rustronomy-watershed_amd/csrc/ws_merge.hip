@@ -694,21 +694,55 @@ __global__ void k_tile_links(const uint32_t *__restrict__ tile_min, int tilesX, 
 // that the 450 seeds of a tile find a root in one load instead of all walking (and compressing) the same chain
 // (a plain walk: the forest is at rest between two launches, and 16 k halving finds on the links' few chains were 29 us
 // of atomics on the same words against 6 us for the walk)
-__global__ void k_tile_roots(uint32_t *tile_min, int ntiles, uint32_t *parent) {
+// mark (optional, zeroed, one word per colour): mark[c] = 1 for every colour the tile links have touched -- a tile's
+// smallest colour or a lake's root; every other colour is still its own root and nobody's parent
+__global__ void k_tile_roots(uint32_t *tile_min, int ntiles, uint32_t *parent, uint32_t *mark) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntiles) return;
   const uint32_t m = tile_min[t];
-  if (m != 0u && m != 0xFFFFFFFFu) tile_min[t] = uf_root(parent, m);
+  if (m != 0u && m != 0xFFFFFFFFu) {
+    const uint32_t r = uf_root(parent, m);
+    tile_min[t] = r;
+    if (mark) { mark[r] = 1u; mark[m] = 1u; }
+  }
 }
 
+// Nearly every seed is a colour nobody has touched yet (its own root, no child: k_tile_roots marks the colours the tile
+// links have touched) that goes under its tile's root, a smaller colour: for those the hook is a PLAIN store, without
+// reading the slot -- nobody else reads or writes it in this launch: a union names a colour only as the seed's own (this
+// thread) or as a tile root (marked), and a find only passes through colours that something was hooked under.  Every
+// other case takes the union.  (54 -> 45 us at 8192^2: what is left is the 16 B per seed the kernel moves.)
 __global__ void k_union_seeds(const uint32_t *__restrict__ seeds_rc, size_t n_seeds, int H, int W, int tilesX,
-                              const uint32_t *__restrict__ tile_min, uint32_t *parent) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                              const uint32_t *__restrict__ tile_min, uint32_t *parent, const uint32_t *__restrict__ tile_root_mark) {
+  // (four seeds per thread and round, each stage's loads in flight together: the kernel is three dependent loads and a
+  // store per seed, and with one seed per thread it was 54 us of waiting for them)
+  constexpr int SU = 4;
   const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (; i < n_seeds; i += step) {
-    const uint2 rc = reinterpret_cast<const uint2 *>(seeds_rc)[i];
-    const uint32_t cmin = tile_min[(size_t)(rc.x / UT) * tilesX + rc.y / UT];
-    if (cmin != 0u && cmin != (uint32_t)(i + 1) && !image_corner((int)rc.x, (int)rc.y, H, W)) uf_union(parent, (uint32_t)(i + 1), cmin);
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n_seeds; i0 += SU * step) {
+    uint2 rc[SU];
+    uint32_t cmin[SU], mark[SU];
+    bool ok[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const size_t i = i0 + u * step;
+      rc[u] = reinterpret_cast<const uint2 *>(seeds_rc)[i < n_seeds ? i : n_seeds - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const size_t i = i0 + u * step;
+      // (a seed outside the plane: the transform has reported it; here it only must not index outside tile_min)
+      ok[u] = i < n_seeds && rc[u].x < (uint32_t)H && rc[u].y < (uint32_t)W;
+      const size_t me = ok[u] ? i + 1 : 0;
+      cmin[u] = tile_min[ok[u] ? (size_t)(rc[u].x / UT) * tilesX + rc[u].y / UT : 0];
+      mark[u] = tile_root_mark ? tile_root_mark[me] : 1u;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const uint32_t me = (uint32_t)(i0 + u * step + 1);
+      if (!ok[u] || cmin[u] == 0u || cmin[u] == me || image_corner((int)rc[u].x, (int)rc[u].y, H, W)) continue;
+      if (cmin[u] < me && mark[u] == 0u) parent[me] = cmin[u];      // (unmarked: parent[me] == me still, see k_tile_roots)
+      else uf_union(parent, me, cmin[u]);
+    }
   }
 }
 
@@ -753,7 +787,7 @@ __global__ __launch_bounds__(256) void k_tile_edges(const uint32_t *__restrict__
 
 // tile_min: union_image_tiles(h, w) words of scratch
 hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *seeds_rc, size_t n_seeds, int h, int w,
-                       uint32_t *parent, uint32_t *tile_min, bool preclassified) {
+                       uint32_t *parent, uint32_t *tile_min, bool preclassified, uint32_t *tile_root_mark) {
   if (h == 0 || w == 0) return hipSuccess;
   const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
   hipError_t e;
@@ -761,11 +795,11 @@ hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *se
   if ((e = hipGetLastError()) != hipSuccess) return e;
   k_tile_links<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx, ty, parent);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent);
+  k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent, tile_root_mark);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (n_seeds) {
-    const int blocks = (int)std::min<size_t>((n_seeds + 255) / 256, 16384);
-    k_union_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n_seeds, h, w, tx, tile_min, parent);
+    const int blocks = (int)std::min<size_t>((n_seeds + 1023) / 1024, 16384);      // four seeds per thread
+    k_union_seeds<<<blocks, 256, 0, s>>>(seeds_rc, n_seeds, h, w, tx, tile_min, parent, tile_root_mark);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     k_tile_edges<<<tx * ty, 256, 0, s>>>(labels, h, w, tx, ty, tile_min, parent);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -837,7 +871,7 @@ hipError_t relabel_final_u32(hipStream_t s, const uint32_t *labels, uint32_t *pa
     // found once per tile by k_tile_roots -- the seeds' unions hook the lake's root under ever smaller colours, a chain
     // ~ln(n) hooks deep that every tile would otherwise walk -- and the other tiles walk what path halving left)
     const int tx = (w + UT - 1) / UT, ty = (h + UT - 1) / UT;
-    k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent);
+    k_tile_roots<<<(tx * ty + 255) / 256, 256, 0, s>>>(tile_min, tx * ty, parent, nullptr);
     hipError_t e0 = hipGetLastError();
     if (e0 != hipSuccess) return e0;
     k_relabel_tiles<<<tx * ty, 256, 0, s>>>(labels, parent, tile_min, out, h, w, tx);

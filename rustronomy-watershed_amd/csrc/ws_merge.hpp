@@ -69,7 +69,8 @@ hipError_t block_colour_roots(hipStream_t s, const uint32_t *labels, int h, int 
 // final level only (coloured <=> label != 0); tile_min: union_image_tiles(h, w) words of scratch
 size_t union_image_tiles(int h, int w);
 hipError_t union_image(hipStream_t s, const uint32_t *labels, const uint32_t *seeds_rc, size_t n_seeds, int h, int w,
-                       uint32_t *parent, uint32_t *tile_min, bool preclassified = false);      // preclassified: resolve_two_launch filled tile_min
+                       uint32_t *parent, uint32_t *tile_min, bool preclassified = false,      // preclassified: resolve_two_launch filled tile_min
+                       uint32_t *tile_root_mark = nullptr);      // optional: n_seeds + 1 zeroed words (k_union_seeds' plain-store hooks)
 // flattens the forest (n_colours entries, entry 0 = "uncoloured" points at itself) and gathers out[i] = root(labels[i])
 hipError_t relabel_final_u32(hipStream_t s, const uint32_t *labels, uint32_t *parent, size_t n_colours, uint32_t *out, size_t n,
                              uint32_t *tile_min = nullptr, int h = 0, int w = 0);      // tile_min: union_image's classification of the h x w plane's tiles (one-lake tiles are filled)
