@@ -218,6 +218,15 @@ int ws_find_local_minima_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, siz
 int ws_segment_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                       const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
                       uint32_t *d_labels);
+/* ws_segment_device in two halves, for pipelines: _begin queues the transform and returns, _end waits for it and
+ * returns its status.  Between the two the context belongs to that transform (no other call on it) and the caller's
+ * buffers must stay as they are.  Only a transform that repeats the previous call's arguments on this context (same
+ * buffers, sizes and seed count: its launches are replayed as one graph) is actually left in flight; any other runs
+ * whole inside _begin.  Two contexts taking turns keep the GPU's queue from running dry between transforms. */
+int ws_segment_device_begin(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                            const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
+                            uint32_t *d_labels);
+int ws_segment_device_end(ws_ctx *ctx);
 /* A stack of independent slices (BASELINE config C4: a cube cut into 2-D slices, as the reference's own
  * integration tests do, tests/integration.rs:267,356): slice k starts at d_cube + k * slice_stride, its
  * seeds are d_seeds_rc[2 * seed_offsets[k] .. 2 * seed_offsets[k+1]) (seed_offsets: n_slices + 1 entries, on

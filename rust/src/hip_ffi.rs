@@ -123,6 +123,9 @@ extern "C" {
         d_out_rc: *mut u32, cap: usize, n_found: *mut usize) -> c_int;
     pub fn ws_segment_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
         d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_segment_device_begin(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_segment_device_end(ctx: *mut ws_ctx) -> c_int;
     pub fn ws_segment_batch_device(ctx: *mut ws_ctx, d_cube: *const u8, n_slices: usize, h: usize, w: usize,
         row_stride: usize, slice_stride: usize, d_seeds_rc: *const u32, seed_offsets: *const usize,
         opt: *const ws_options, d_labels: *mut u32, failed_slice: *mut usize) -> c_int;

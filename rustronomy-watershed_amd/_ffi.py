@@ -93,6 +93,8 @@ SIGNATURES = {
     "ws_merge_transform_stub": (ctypes.c_int, [sz, sz, vp]),
     "ws_find_local_minima_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
     "ws_segment_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_segment_device_begin": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_segment_device_end": (ctypes.c_int, [vp]),
     "ws_segment_batch_device": (ctypes.c_int, [vp, vp, sz, sz, sz, sz, sz, vp, ctypes.POINTER(ctypes.c_size_t),
                                                ctypes.POINTER(Options), vp, ctypes.POINTER(ctypes.c_size_t)]),
     "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),

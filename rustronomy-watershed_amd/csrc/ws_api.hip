@@ -51,6 +51,8 @@ struct ws_ctx {
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
   hipStream_t copy_stream = nullptr;    // carries the per-pass flag read-backs
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t async_ev = nullptr;      // end of the graph a ws_segment_device_begin left in flight
+  bool stats_no_wait = false;         // ws_segment_device_end: the stream may hold another context's work behind ours
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<TimedSpan> spans;
@@ -66,6 +68,12 @@ struct ws_ctx {
   size_t block_h = 0, block_w = 0;
   size_t batch_max_px = 0x7FFFFFFFull;      // largest stack of slices run as one transform (ws_ctx_set_batch_pixel_limit)
   size_t seam_min_px = (size_t)1 << 24;     // smallest plane whose pass 1 is a seam repair (ws_ctx_set_seam_repair_min_pixels)
+  // ws_segment_device_begin / _end: a transform whose replayed graph has been launched and whose host half (the wait, the
+  // look at the convergence and error words, more passes if the flood needs them) is still to come
+  enum AsyncPhase { ASYNC_NONE = 0, ASYNC_BEGIN, ASYNC_LAUNCHED, ASYNC_DONE, ASYNC_RESUME };
+  int async_phase = ASYNC_NONE;
+  int async_rc = 0;
+  struct { const uint8_t *d_img; size_t h, w, stride; const uint32_t *d_seeds; size_t n_seeds; ws_options opt; uint32_t *d_labels; } async_args = {};
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
   // the optimistic part of a transform (seed tables, first passes, gated resolve, read-backs) as a replayable graph
   struct GraphKey {
@@ -197,6 +205,8 @@ void stats_begin(ws_ctx *c) {
 }
 
 int stats_end(ws_ctx *c) {
+  // (the second half of a begun transform has waited for ITS work already; the stream may hold the next context's)
+  if (c->stats_no_wait) { c->stats.ms_total = 0.0f; return WS_OK; }
   HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
   HIP_TRY(c, hipEventSynchronize(c->ev_end));
   float ms = 0;
@@ -298,6 +308,7 @@ int pass_loop(ws_ctx *c, uint32_t *d_flags, size_t ntiles, uint32_t *passes_out,
   return WS_OK;
 }
 
+constexpr int WS_INTERNAL_PENDING = 0x7fff;      // run_fused_form -> ws_segment_device_begin: graph launched, host half pending (never leaves the library)
 constexpr uint32_t GRAPH_PASSES = 5;      // passes inside the graph; the resolve is gated on the last one (the bench field: pass 3 still moves a few tiles, pass 4 finds nothing -- a sixth pass was 6 us of idle launch)
 
 inline const uint32_t *edge_slot(const uint32_t *d_flags, uint32_t pass) {
@@ -350,12 +361,15 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   key.generation = c->buffer_generation;
   const bool graph_ok = use_graph && c->stream != nullptr && !c->graph_unusable && tables && n != 0 && n < 0x80000000ull && !c->profiling && c->misc_clean &&
                         c->debug_max_iters == 0xFFFFFFFFu;
-  if (graph_ok && c->graph_exec && key == c->graph_key) graph_mode = 1;
+  const bool resume = c->async_phase == ws_ctx::ASYNC_RESUME;      // ws_segment_device_end: the graph of this very call is in flight
+  if (resume) c->async_phase = ws_ctx::ASYNC_NONE;      // (consumed: a repeat with painted seeds after a wrong guess is an ordinary run)
+  if (resume) graph_mode = 1;
+  else if (graph_ok && c->graph_exec && key == c->graph_key) graph_mode = 1;
   else if (graph_ok && key == c->seen_key) graph_mode = 2;
-  c->seen_key = graph_ok ? key : ws_ctx::GraphKey();
+  if (!resume) c->seen_key = graph_ok ? key : ws_ctx::GraphKey();
   if (graph_mode != 0) {
     if ((rc = ensure(c, c->refs, resolve_ref_capacity(ph, pw) * sizeof(uint32_t)))) return rc;
-    if (c->buffer_generation != key.generation) graph_mode = 0;      // that allocation moved a buffer: next time
+    if (c->buffer_generation != key.generation && !resume) graph_mode = 0;      // that allocation moved a buffer: next time
   }
   if (graph_mode == 2) {
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -398,8 +412,15 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     *mispredicted = false;
     c->misc_clean = false;
     c->stats.graph_launches = 1;
-    HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!resume) HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    if (c->async_phase == ws_ctx::ASYNC_BEGIN && graph_mode == 1) {      // ws_segment_device_begin: the host half waits for _end
+      HIP_TRY(c, hipEventRecord(c->async_ev, c->stream));
+      c->async_phase = ws_ctx::ASYNC_LAUNCHED;
+      return WS_INTERNAL_PENDING;
+    }
+    // (_end waits for the graph's own end, not for the stream: another context may have queued its transform behind it)
+    if (resume) HIP_TRY(c, hipEventSynchronize(c->async_ev));
+    else HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else {
     Span sp(c, KC_OTHER);
     // The error words (ring overflow, seed out of bounds, list unsorted / not strict) are only ever
@@ -742,6 +763,7 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   if (const char *e = tuning_env("WS_DEBUG_MAXIT")) c->debug_max_iters = (uint32_t)std::atoi(e);
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->async_ev, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->kern_ev[i], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
@@ -769,6 +791,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   for (int i = 0; i < COUNTER_RING; ++i) if (c->kern_ev[i]) (void)hipEventDestroy(c->kern_ev[i]);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->async_ev) (void)hipEventDestroy(c->async_ev);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -873,9 +896,8 @@ int ws_segment_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size
   return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels);
 }
 
-int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
-                      size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
-  if (!c) return WS_ERR_BAD_ARG;
+static int segment_device_body(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                               size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
   size_t ph, pw;
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
   if (rc) return rc;
@@ -894,8 +916,47 @@ int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_
                    [](uint32_t, const uint32_t *) { return (int)WS_OK; }, padded);
   else
     rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, d_labels, padded);
-  if (rc) return rc;
+  if (rc) return rc;      // (WS_INTERNAL_PENDING included: ws_segment_device_begin)
   return stats_end(c);
+}
+
+int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                      size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "a transform begun with ws_segment_device_begin has not been ended");
+  return segment_device_body(c, d_img, h, w, stride, d_seeds_rc, n_seeds, opt, d_labels);
+}
+
+// The two halves of ws_segment_device.  _begin queues the transform and returns; _end waits for it and reports its
+// status.  What can be queued without the host looking is the replayed graph of a transform that repeats the previous
+// one's arguments (run_fused_form): any other call runs whole inside _begin.  Between the two the context belongs to the
+// transform: no other call on it, and the caller's buffers must stay as they are (a flood that needs more passes than the
+// graph holds goes on inside _end).  Two contexts that take turns keep the GPU's queue from running dry between
+// transforms -- the host's wait-and-relaunch is ~15 us of a 0.55 ms transform at 8192^2.
+int ws_segment_device_begin(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                            size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  if (!c || !opt) return WS_ERR_BAD_ARG;
+  if (c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "ws_segment_device_begin: the previous transform has not been ended");
+  c->async_args = {d_img, h, w, stride, d_seeds_rc, n_seeds, *opt, d_labels};
+  c->async_phase = ws_ctx::ASYNC_BEGIN;
+  const int rc = segment_device_body(c, d_img, h, w, stride, d_seeds_rc, n_seeds, opt, d_labels);
+  if (rc == WS_INTERNAL_PENDING && c->async_phase == ws_ctx::ASYNC_LAUNCHED) return WS_OK;
+  c->async_phase = ws_ctx::ASYNC_DONE;      // ran whole (or failed): _end hands the status over
+  c->async_rc = rc == WS_INTERNAL_PENDING ? (int)WS_ERR_UNSUPPORTED : rc;
+  return WS_OK;
+}
+
+int ws_segment_device_end(ws_ctx *c) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (c->async_phase == ws_ctx::ASYNC_DONE) { c->async_phase = ws_ctx::ASYNC_NONE; return c->async_rc; }
+  if (c->async_phase != ws_ctx::ASYNC_LAUNCHED) return fail(c, WS_ERR_BAD_ARG, "ws_segment_device_end without ws_segment_device_begin");
+  c->async_phase = ws_ctx::ASYNC_RESUME;
+  c->stats_no_wait = true;
+  const auto a = c->async_args;
+  const int rc = segment_device_body(c, a.d_img, a.h, a.w, a.stride, a.d_seeds, a.n_seeds, &a.opt, a.d_labels);
+  c->stats_no_wait = false;
+  c->async_phase = ws_ctx::ASYNC_NONE;
+  return rc == WS_INTERNAL_PENDING ? (int)WS_ERR_UNSUPPORTED : rc;
 }
 
 int ws_last_arrival_device(ws_ctx *c, const uint32_t **d_keys, size_t *h, size_t *w) {

@@ -58,6 +58,28 @@ class DeviceEngine:
                                                     out.data_ptr()))
         return out
 
+    def segment_begin(self, img, seeds, out, max_level=254, edge=False, seed_shift=False):
+        """First half of segment() (ws_segment_device_begin): queues the transform and returns.  The engine is busy until
+        segment_end(); img, seeds and out must stay alive and unchanged until then.  Two engines taking turns keep the
+        GPU fed between transforms."""
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        assert seeds.dtype == torch.int32 and seeds.is_cuda and (seeds.numel() == 0 or seeds.is_contiguous())
+        assert out.dtype == torch.int32 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == self._plane(img, edge)
+        h, w = img.shape
+        opt = self.options(max_level, edge, None, seed_shift)
+        ns = seeds.shape[0] if seeds.dim() == 2 else 0
+        self._pending = (img, seeds, out)
+        self.ctx.check(_ffi.lib().ws_segment_device_begin(self.ctx.handle, img.data_ptr(), h, w, w,
+                                                          seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),
+                                                          out.data_ptr()))
+        return out
+
+    def segment_end(self):
+        """Second half: waits for the transform begun with segment_begin() and raises if it failed."""
+        pending, self._pending = getattr(self, "_pending", None), None
+        self.ctx.check(_ffi.lib().ws_segment_device_end(self.ctx.handle))
+        return pending[2] if pending else None
+
     def segment_batch(self, cube, seeds, seed_offsets, max_level=254, edge=False, out=None, seed_shift=False):
         """A stack of independent slices (config C4).  cube: (S, H, W) uint8; seeds: all slices' (row, col) pairs
         concatenated, int32 (n, 2); seed_offsets: S + 1 host integers.  Returns (S, H', W') int32 labels."""

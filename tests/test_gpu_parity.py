@@ -661,3 +661,63 @@ def test_seam_repair_flow_on_stacked_slices(pkg, s, h, w):
             assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
     finally:
         eng.ctx.set_seam_repair_min_pixels(0)
+
+
+def test_segment_begin_end_pipelined_on_two_contexts(pkg):
+    # ws_segment_device_begin / _end: two engines on two streams take turns, every transform queued behind the other
+    # engine's one before the host has waited for anything.  Same labels as the one-call form; a flood that needs more
+    # passes than the replayed graph holds is finished inside _end; misuse is an error, not a hang.
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    for same_stream in (False, True):
+        _pipelined_begin_end(pkg, dev, torch, same_stream)
+
+
+def _pipelined_begin_end(pkg, dev, torch, same_stream):
+    # two streams: the next transform waits for the other context's by an event; one stream: stream order does it, and
+    # _end must wait for its own graph only (the other context's transform is queued behind it)
+    streams = [torch.cuda.Stream(0), torch.cuda.Stream(0)]
+    if same_stream:
+        streams[1] = streams[0]
+    engines = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            engines.append(dev.DeviceEngine(0))
+    for himg in (cases.field(300, 772, 5), cases.smooth_field(520, 1028, 31, octaves=5)):
+        hseeds = ol.find_local_minima(himg)
+        want = ol.segment_arrival(himg, hseeds)
+        img = torch.from_numpy(himg).to(engines[0].device)
+        seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(engines[0].device).contiguous()
+        outs = [torch.zeros(himg.shape, dtype=torch.int32, device=engines[0].device) for _ in engines]
+        torch.cuda.synchronize()
+        events = [torch.cuda.Event(), torch.cuda.Event()]
+        pending = [False, False]
+        replayed = 0
+        for k in range(10):
+            i = k & 1
+            if pending[i]:
+                engines[i].segment_end()
+                replayed += engines[i].stats()["graph_launches"]
+                assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), (k, himg.shape)
+                outs[i].zero_()
+                torch.cuda.synchronize()
+            if k > 0 and not same_stream:
+                streams[i].wait_event(events[1 - i])
+            engines[i].segment_begin(img, seeds, outs[i])
+            events[i].record(streams[i])
+            pending[i] = True
+        for i in (0, 1):
+            engines[i].segment_end()
+            assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), ("tail", i)
+        assert replayed >= 4        # from its third call on an engine replays its graph: those were left in flight
+    # misuse
+    with pytest.raises(pkg.WatershedError):
+        engines[0].segment_end()
+    engines[0].segment_begin(img, seeds, outs[0])
+    with pytest.raises(pkg.WatershedError):
+        engines[0].segment_begin(img, seeds, outs[0])
+    with pytest.raises(pkg.WatershedError):
+        engines[0].segment(img, seeds, out=outs[0])
+    engines[0].segment_end()
+    assert (engines[0].segment(img, seeds, out=outs[0]).cpu().numpy().view(np.uint32) == want).all()
