@@ -47,6 +47,7 @@ struct ws_ctx {
   DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
   DevBuf uf_parent, uf_size, uf_hooked, uf_death, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
+  uint32_t *pinned_dev = nullptr;  // the same words as the device sees them (nullptr: not mapped, copies only)
   hipEvent_t ring_ev[COUNTER_RING]{};   // flag slot copied to the host
   hipEvent_t kern_ev[COUNTER_RING]{};   // pass kernel finished
   hipStream_t copy_stream = nullptr;    // carries the per-pass flag read-backs
@@ -390,10 +391,14 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
                              c->tile_min_out, edge_slot(flags, last), slice_h, flags + FLAG_OVERFLOW, flags + FLAG_SEED_ERR);
-    if (e == hipSuccess)
+    // the read-backs: the lookahead pass's convergence slot and the error words
+    if (e == hipSuccess && c->pinned_dev)
+      e = words_to_host(c->stream, edge_slot(flags, last), FLAG_SLOT, c->pinned_dev + FLAG_EDGE + (last % COUNTER_RING) * FLAG_SLOT,
+                        flags + FLAG_OVERFLOW, FLAG_NERR, c->pinned_dev + FLAG_OVERFLOW);
+    if (e == hipSuccess && !c->pinned_dev)
       e = hipMemcpyAsync(&c->pinned[FLAG_EDGE + (last % COUNTER_RING) * FLAG_SLOT], edge_slot(flags, last), FLAG_SLOT * sizeof(uint32_t),
                          hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess)
+    if (e == hipSuccess && !c->pinned_dev)
       e = hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, FLAG_NERR * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
     if (e == hipSuccess && e2 == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
@@ -762,6 +767,7 @@ static int ctx_create(int device, void *stream, bool own, ws_ctx **out) {
   c->own_stream = own;
   if (const char *e = tuning_env("WS_DEBUG_MAXIT")) c->debug_max_iters = (uint32_t)std::atoi(e);
   ok = ok && hipHostMalloc((void **)&c->pinned, FLAG_WORDS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok && hipHostGetDevicePointer((void **)&c->pinned_dev, c->pinned, 0) != hipSuccess) { (void)hipGetLastError(); c->pinned_dev = nullptr; }
   ok = ok && hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->async_ev, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < COUNTER_RING; ++i) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;

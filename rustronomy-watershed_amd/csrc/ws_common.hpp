@@ -91,6 +91,8 @@ struct PassFlags {
 
 // --- launch wrappers (ws_kernels.hip) ---------------------------------------------------
 hipError_t fill_u32(hipStream_t s, uint32_t *p, size_t n, uint32_t v);
+// host_a / host_b: DEVICE pointers to pinned host memory (hipHostGetDevicePointer)
+hipError_t words_to_host(hipStream_t s, const uint32_t *a, uint32_t na, uint32_t *host_a, const uint32_t *b, uint32_t nb, uint32_t *host_b);
 hipError_t zero3(hipStream_t s, uint32_t *a, size_t na, uint32_t *b, size_t nb, uint32_t *c, size_t nc);   // one launch
 hipError_t random_field(hipStream_t s, uint8_t *img, size_t stride, int h, int w, uint64_t seed);
 hipError_t scatter_seeds(hipStream_t s, const uint32_t *seeds_rc, const uint32_t *colours, size_t n, int ph, int pw,

@@ -724,6 +724,20 @@ hipError_t resolve_pass(hipStream_t s, const uint32_t *keys, uint32_t *labels, i
   return hipGetLastError();
 }
 
+// Two short runs of flag words into the host's pinned mirror (device-visible host memory) by ONE small launch: inside a
+// replayed graph two device-to-host copy nodes were blit kernels of their own with barriers around them, idle time at the
+// end of every transform.
+__global__ void k_words_to_host(const uint32_t *__restrict__ a, uint32_t na, uint32_t *ha, const uint32_t *__restrict__ b, uint32_t nb,
+                                uint32_t *hb) {
+  for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) ha[i] = a[i];
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) hb[i] = b[i];
+}
+
+hipError_t words_to_host(hipStream_t s, const uint32_t *a, uint32_t na, uint32_t *host_a, const uint32_t *b, uint32_t nb, uint32_t *host_b) {
+  k_words_to_host<<<1, 64, 0, s>>>(a, na, host_a, b, nb, host_b);
+  return hipGetLastError();
+}
+
 // ------------------------------------ fused engine: label resolve, two-launch form ----
 //
 // Same forest as k_resolve, but resolved without iterating over launches:
