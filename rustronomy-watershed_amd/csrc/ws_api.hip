@@ -54,6 +54,7 @@ struct ws_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t async_ev = nullptr;      // end of the graph a ws_segment_device_begin left in flight
   bool stats_no_wait = false;         // ws_segment_device_end: the stream may hold another context's work behind ours
+  bool graph_sufficed = false;        // the last run_fused_form: replayed graph, at its fixpoint after the graph's passes, tables valid
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<TimedSpan> spans;
@@ -346,6 +347,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   uint32_t *seed_mask = tables ? (uint32_t *)c->seed_tab.p : nullptr, *word_base = tables ? seed_mask + nwords : nullptr;
   c->have_keys = false;
   *mispredicted = false;
+  c->graph_sufficed = false;
 
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
@@ -525,6 +527,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   }
   if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
   c->misc_clean = c->pinned[FLAG_UNSORTED] == 0 && c->pinned[FLAG_NONSTRICT] == 0;
+  c->graph_sufficed = graph_mode != 0 && converged_at == GRAPH_PASSES - 1;
   c->have_keys = true;
   c->last_h = ph;
   c->last_w = pw;
@@ -1636,18 +1639,34 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   if ((rc = ensure(c, c->counts, std::max<size_t>(union_image_tiles((int)ph, (int)pw), 1) * sizeof(uint32_t)))) return rc;
   c->tile_min_out = (uint32_t *)c->counts.p;      // the resolve kernel classifies the tiles while it has them in registers
   c->tile_min_filled = false;
-  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
-  c->tile_min_out = nullptr;
-  if (rc) return rc;
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
-  HIP_TRY(c, uf_init(c->stream, (uint32_t *)c->uf_parent.p, (uint32_t *)c->uf_size.p, n_seeds + 1));
-  {
+  auto unions_and_relabel = [&](bool preclassified) -> int {
+    HIP_TRY(c, uf_init(c->stream, (uint32_t *)c->uf_parent.p, (uint32_t *)c->uf_size.p, n_seeds + 1));
     Span sp(c, KC_OTHER);
     // at the final level a pixel is coloured exactly when its segmenting label is non-zero: no stamps needed
     HIP_TRY(c, union_image(c->stream, seg, seeds, n_seeds, (int)ph, (int)pw, (uint32_t *)c->uf_parent.p, (uint32_t *)c->counts.p,
-                           c->tile_min_filled, (uint32_t *)c->uf_size.p));      // (uf_init has just zeroed uf_size: the tile-root marks)
+                           preclassified, (uint32_t *)c->uf_size.p));      // (uf_init has just zeroed uf_size: the tile-root marks)
     HIP_TRY(c, relabel_final_u32(c->stream, seg, (uint32_t *)c->uf_parent.p, n_seeds + 1, d_labels, n, (uint32_t *)c->counts.p, (int)ph, (int)pw));
+    return WS_OK;
+  };
+  // A call that replays the previous call's graph (run_fused_form: same buffers, sizes and seed count) queues its unions
+  // and the relabel behind the graph BEFORE the host has looked at the graph's convergence word -- the host's wait and
+  // look were ~18 us of idle GPU in the middle of every transform.  If the flood then turns out to need more passes (or
+  // the seed tables were not valid), the unions ran on the previous call's labels and tile classes -- the same buffers,
+  // valid colours of the same seed count -- and are simply done again after the real resolve.
+  c->async_phase = ws_ctx::ASYNC_BEGIN;
+  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
+  bool speculated = false;
+  if (rc == WS_INTERNAL_PENDING && c->async_phase == ws_ctx::ASYNC_LAUNCHED) {
+    if ((rc = unions_and_relabel(true))) { c->async_phase = ws_ctx::ASYNC_NONE; c->tile_min_out = nullptr; return rc; }
+    speculated = true;
+    c->async_phase = ws_ctx::ASYNC_RESUME;      // the host half: waits for the graph's end event, reads its words, goes on if it must
+    rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
   }
+  c->async_phase = ws_ctx::ASYNC_NONE;
+  c->tile_min_out = nullptr;
+  if (rc) return rc == WS_INTERNAL_PENDING ? fail(c, WS_ERR_UNSUPPORTED, "internal: transform left pending") : rc;
+  if (!(speculated && c->graph_sufficed) && (rc = unions_and_relabel(c->tile_min_filled))) return rc;
   c->stats.merge_levels = 1;
   return stats_end(c);
 }

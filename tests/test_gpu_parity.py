@@ -462,6 +462,20 @@ def test_graph_replay_of_repeated_transforms(pkg):
             m = eng.merge(d_img, d_seeds, out=mout).cpu().numpy().view(np.uint32)
             assert (m == ol.merge_arrival(imgs[0], lists[0][:n])).all(), rep
         assert eng.stats()["graph_launches"] == 1
+        # ... with its unions queued behind the graph before the host has looked (ws_merge_device): contents that change
+        # between replays, and a flood the graph's passes do not finish (the unions then ran on stale labels and are redone)
+        for rep in range(6):
+            k = rep % 3
+            d_img.copy_(torch.from_numpy(imgs[k]))
+            d_seeds.copy_(torch.from_numpy(lists[k][:n]).to(torch.int32))
+            m = eng.merge(d_img, d_seeds, out=mout).cpu().numpy().view(np.uint32)
+            assert (m == ol.merge_arrival(imgs[k], lists[k][:n])).all(), rep
+        d_img.copy_(torch.from_numpy(maze))
+        for rep in range(4):
+            m = eng.merge(d_img, d_one, out=mout).cpu().numpy().view(np.uint32)
+            assert eng.stats()["relax_passes"] > 8
+            assert (m == ol.merge_arrival(maze, lists[3])).all(), rep
+        assert eng.stats()["graph_launches"] == 1
         himgs, hseeds = _batch_case(4, 32, 64, 900)
         offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
         cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
