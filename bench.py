@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--cpu-size", type=int, default=4096, help="side of the CPU-baseline sample field (0 = skip)")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / cpu_baseline")
+    ap.add_argument("--contexts", type=int, default=4, help="headline: engine contexts that take turns, each on its own stream (1: as --no-pipeline)")
+    ap.add_argument("--one-stream", action="store_true", help="headline: all contexts on one stream (transforms queue up, never overlap)")
     ap.add_argument("--no-pipeline", action="store_true", help="headline: one context, every transform waited for before the next is queued (the default takes turns on two contexts: ws_segment_device_begin / _end)")
     return ap.parse_args()
 
@@ -221,25 +223,32 @@ def run(args):
         if cfg == "c3":
             def step():
                 eng.merge(img, seeds, out=labels)       # segmenting flood + one union pass over the image + relabel
-        elif args.no_pipeline or args.engine == "sweep":
+        elif args.no_pipeline or args.contexts < 2 or args.engine == "sweep":
             def step():
                 eng.segment(img, seeds, out=labels)
         else:
-            # Two contexts on ONE stream take turns (ws_segment_device_begin / _end): transform k is queued behind
-            # transform k - 1 of the other context before the host has waited for anything, so the GPU's queue never runs
-            # dry between transforms (one context: ~15 us of a 0.55 ms transform go to the host's wait-and-relaunch).
-            # Every step is still one whole transform of the same field into its context's own label plane.
-            eng_b = dev.DeviceEngine(dev_index, engine=pkg.ENGINE_FUSED)
-            pipe_engines = [eng, eng_b]
-            pipe_labels = [labels, torch.empty_like(labels)]
-            pipe = {"k": 0, "pending": [False, False]}
+            # `--contexts` engine contexts take turns (ws_segment_device_begin / _end), each on a stream of its own: transform
+            # k is queued before transform k - 1 has been waited for, and transforms of different contexts may overlap on
+            # the GPU -- where one transform leaves CUs idle (its latency-bound launches: seam strips, passes 2-4, the
+            # chase) another one's kernels run.  Every step is still one whole transform of the same field into its
+            # context's own label plane; a context's previous transform is waited for before its next one is queued.
+            # (`--one-stream`: all contexts on one stream, so that transforms only queue up behind each other.)
+            pipe_engines, pipe_labels = [eng], [labels]
+            for _ in range(args.contexts - 1):
+                if args.one_stream:
+                    pipe_engines.append(dev.DeviceEngine(dev_index, engine=pkg.ENGINE_FUSED))
+                else:
+                    with torch.cuda.stream(torch.cuda.Stream(dev_index)):
+                        pipe_engines.append(dev.DeviceEngine(dev_index, engine=pkg.ENGINE_FUSED))
+                pipe_labels.append(torch.empty_like(labels))
+            pipe = {"k": 0, "pending": [False] * args.contexts}
             for e_, l_ in zip(pipe_engines, pipe_labels):      # third call on: the context replays its graph
                 for _ in range(3):
                     e_.segment(img, seeds, out=l_)
             torch.cuda.synchronize()
 
             def step():
-                i = pipe["k"] & 1
+                i = pipe["k"] % args.contexts
                 if pipe["pending"][i]:
                     pipe_engines[i].segment_end()
                 pipe_engines[i].segment_begin(img, seeds, pipe_labels[i])
@@ -247,7 +256,7 @@ def run(args):
                 pipe["k"] += 1
 
             def drain():
-                for i in (0, 1):
+                for i in range(args.contexts):
                     if pipe["pending"][i]:
                         pipe_engines[i].segment_end()
                         pipe["pending"][i] = False
@@ -456,12 +465,19 @@ def run(args):
                             "launch": (("every step runs all of its kernels; the seed tables, the first 5 passes and the resolve "
                                         "are replayed as one hipGraph because the buffers repeat (stream launches: +1-2 %)")
                                        if replayed else "stream launches") +
-                                      ("; two contexts on one stream take turns (ws_segment_device_begin / _end), each transform queued "
-                                       "behind the other context's one before the host waits -- one context, every transform waited "
-                                       f"for before the next is queued: {ms_one_context:.4f} ms per step" if ms_one_context is not None else "")},
+                                      (f"; {args.contexts} contexts take turns (ws_segment_device_begin / _end), "
+                                       + ("all on one stream: a transform is queued behind the one before it before the host waits"
+                                          if args.one_stream else
+                                          "each on its own stream: a transform is queued before the one before it has been waited for, and "
+                                          "transforms of different contexts overlap on the GPU (throughput, not the latency of one transform)")
+                                       + f" -- one context, every transform waited for before the next is queued: {ms_one_context:.4f} ms per step"
+                                       if ms_one_context is not None else "")},
                            **units),
             "roofline": roof,
         }
+        if ms_one_context is not None:      # the time of ONE transform when nothing else is in flight (the one-call form)
+            out["config"]["contexts_in_flight"] = args.contexts
+            out["config"]["ms_one_transform_alone"] = round(ms_one_context, 4)
         if labels is not None:
             out["config"]["coloured_px"] = int((labels != 0).sum().item())
         extras = cfg == "headline" and world == 1 and not args.no_extras

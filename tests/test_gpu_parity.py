@@ -684,13 +684,15 @@ def test_segment_begin_end_pipelined_on_two_contexts(pkg):
     import importlib
     import torch
     dev = importlib.import_module("rustronomy_watershed_amd.device")
-    for same_stream in (False, True):
-        _pipelined_begin_end(pkg, dev, torch, same_stream)
+    for mode in ("events", "one_stream", "concurrent"):
+        _pipelined_begin_end(pkg, dev, torch, mode)
 
 
-def _pipelined_begin_end(pkg, dev, torch, same_stream):
-    # two streams: the next transform waits for the other context's by an event; one stream: stream order does it, and
-    # _end must wait for its own graph only (the other context's transform is queued behind it)
+def _pipelined_begin_end(pkg, dev, torch, mode):
+    # "events": two streams, the next transform waits for the other context's by an event; "one_stream": stream order does
+    # it, and _end must wait for its own graph only (the other context's transform is queued behind it); "concurrent": two
+    # streams and no order between them -- the two contexts' transforms overlap on the GPU (what bench.py does)
+    same_stream = mode == "one_stream"
     streams = [torch.cuda.Stream(0), torch.cuda.Stream(0)]
     if same_stream:
         streams[1] = streams[0]
@@ -716,7 +718,7 @@ def _pipelined_begin_end(pkg, dev, torch, same_stream):
                 assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), (k, himg.shape)
                 outs[i].zero_()
                 torch.cuda.synchronize()
-            if k > 0 and not same_stream:
+            if k > 0 and mode == "events":
                 streams[i].wait_event(events[1 - i])
             engines[i].segment_begin(img, seeds, outs[i])
             events[i].record(streams[i])
