@@ -220,12 +220,10 @@ def run(args):
         n_seeds = int(seeds.shape[0])
         px_per_step_all_ranks = world * H * W
         scaling = "weak"
-        if cfg == "c3":
+        merging = cfg == "c3"       # segmenting flood + one union pass over the image + relabel
+        if args.no_pipeline or args.contexts < 2 or args.engine == "sweep":
             def step():
-                eng.merge(img, seeds, out=labels)       # segmenting flood + one union pass over the image + relabel
-        elif args.no_pipeline or args.contexts < 2 or args.engine == "sweep":
-            def step():
-                eng.segment(img, seeds, out=labels)
+                (eng.merge if merging else eng.segment)(img, seeds, out=labels)
         else:
             # `--contexts` engine contexts take turns (ws_segment_device_begin / _end), each on a stream of its own: transform
             # k is queued before transform k - 1 has been waited for, and transforms of different contexts may overlap on
@@ -244,21 +242,21 @@ def run(args):
             pipe = {"k": 0, "pending": [False] * args.contexts}
             for e_, l_ in zip(pipe_engines, pipe_labels):      # third call on: the context replays its graph
                 for _ in range(3):
-                    e_.segment(img, seeds, out=l_)
+                    (e_.merge if merging else e_.segment)(img, seeds, out=l_)
             torch.cuda.synchronize()
 
             def step():
                 i = pipe["k"] % args.contexts
                 if pipe["pending"][i]:
-                    pipe_engines[i].segment_end()
-                pipe_engines[i].segment_begin(img, seeds, pipe_labels[i])
+                    (pipe_engines[i].merge_end if merging else pipe_engines[i].segment_end)()
+                (pipe_engines[i].merge_begin if merging else pipe_engines[i].segment_begin)(img, seeds, pipe_labels[i])
                 pipe["pending"][i] = True
                 pipe["k"] += 1
 
             def drain():
                 for i in range(args.contexts):
                     if pipe["pending"][i]:
-                        pipe_engines[i].segment_end()
+                        (pipe_engines[i].merge_end if merging else pipe_engines[i].segment_end)()
                         pipe["pending"][i] = False
                 pipe["k"] = 0
             pipelined = True
@@ -334,7 +332,7 @@ def run(args):
         # the same K steps on ONE context, every transform waited for before the next is queued (what a caller of the
         # one-call form gets): reported beside the pipelined figure, never as `value`
         def step():
-            eng.segment(img, seeds, out=labels)
+            (eng.merge if merging else eng.segment)(img, seeds, out=labels)
         for _ in range(3):
             step()
         barrier()

@@ -245,6 +245,11 @@ int ws_segment_batch_device(ws_ctx *ctx, const uint8_t *d_cube, size_t n_slices,
 int ws_merge_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                     const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
                     uint32_t *d_labels);
+/* ... in two halves, as ws_segment_device_begin / _end (same rules). */
+int ws_merge_device_begin(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
+                          const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt,
+                          uint32_t *d_labels);
+int ws_merge_device_end(ws_ctx *ctx);
 /* Watershed::transform_to_list with everything in HBM: the image, the u32 seed pairs and the lake RECORDS (d_lakes: cap
  * records in the caller's device buffer; at 1024^2 they are 155 MB that the host form spends most of its time copying).
  * Only the per-level offsets (max_water_level + 2) and uncoloured counts (max_water_level + 1) go to the host arrays.

@@ -131,6 +131,9 @@ extern "C" {
         opt: *const ws_options, d_labels: *mut u32, failed_slice: *mut usize) -> c_int;
     pub fn ws_merge_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
         d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_merge_device_begin(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_labels: *mut u32) -> c_int;
+    pub fn ws_merge_device_end(ctx: *mut ws_ctx) -> c_int;
     pub fn ws_transform_to_list_device(ctx: *mut ws_ctx, merging: c_int, d_img: *const u8, h: usize, w: usize,
         row_stride: usize, d_seeds_rc: *const u32, n_seeds: usize, opt: *const ws_options, d_lakes: *mut ws_lake,
         cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64) -> c_int;

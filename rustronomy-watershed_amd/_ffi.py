@@ -98,6 +98,8 @@ SIGNATURES = {
     "ws_segment_batch_device": (ctypes.c_int, [vp, vp, sz, sz, sz, sz, sz, vp, ctypes.POINTER(ctypes.c_size_t),
                                                ctypes.POINTER(Options), vp, ctypes.POINTER(ctypes.c_size_t)]),
     "ws_merge_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_merge_device_begin": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_merge_device_end": (ctypes.c_int, [vp]),
     "ws_last_arrival_device": (ctypes.c_int, [vp, ctypes.POINTER(vp), szp, szp]),
     "ws_copy_last_arrival_device": (ctypes.c_int, [vp, vp, sz]),
     "ws_level_snapshot_device": (ctypes.c_int, [vp, vp, ctypes.c_uint8, vp]),

@@ -75,6 +75,7 @@ struct ws_ctx {
   enum AsyncPhase { ASYNC_NONE = 0, ASYNC_BEGIN, ASYNC_LAUNCHED, ASYNC_DONE, ASYNC_RESUME };
   int async_phase = ASYNC_NONE;
   int async_rc = 0;
+  bool async_merge = false;      // the transform in flight was begun with ws_merge_device_begin
   struct { const uint8_t *d_img; size_t h, w, stride; const uint32_t *d_seeds; size_t n_seeds; ws_options opt; uint32_t *d_labels; } async_args = {};
   uint32_t debug_max_iters = 0xFFFFFFFFu;   // WS_DEBUG_MAXIT: timing experiments only (results wrong when it bites)
   // the optimistic part of a transform (seed tables, first passes, gated resolve, read-backs) as a replayable graph
@@ -957,6 +958,7 @@ int ws_segment_device_begin(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w,
 
 int ws_segment_device_end(ws_ctx *c) {
   if (!c) return WS_ERR_BAD_ARG;
+  if (c->async_merge) return fail(c, WS_ERR_BAD_ARG, "ws_segment_device_end: the transform in flight was begun with ws_merge_device_begin");
   if (c->async_phase == ws_ctx::ASYNC_DONE) { c->async_phase = ws_ctx::ASYNC_NONE; return c->async_rc; }
   if (c->async_phase != ws_ctx::ASYNC_LAUNCHED) return fail(c, WS_ERR_BAD_ARG, "ws_segment_device_end without ws_segment_device_begin");
   c->async_phase = ws_ctx::ASYNC_RESUME;
@@ -1617,9 +1619,10 @@ int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, s
   return WS_OK;
 }
 
-int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
-                    size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
-  if (!c) return WS_ERR_BAD_ARG;
+// half: 0 the whole call; 1 ws_merge_device_begin (returns WS_INTERNAL_PENDING when the graph and the speculative unions
+// have been queued and the host half is still to come); 2 ws_merge_device_end (that host half)
+static int merge_device_body(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                             size_t n_seeds, const ws_options *opt, uint32_t *d_labels, int half) {
   size_t ph, pw;
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
   if (rc) return rc;
@@ -1654,12 +1657,15 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   // look were ~18 us of idle GPU in the middle of every transform.  If the flood then turns out to need more passes (or
   // the seed tables were not valid), the unions ran on the previous call's labels and tile classes -- the same buffers,
   // valid colours of the same seed count -- and are simply done again after the real resolve.
-  c->async_phase = ws_ctx::ASYNC_BEGIN;
-  rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
+  if (half != 2) {
+    c->async_phase = ws_ctx::ASYNC_BEGIN;
+    rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
+  }
   bool speculated = false;
-  if (rc == WS_INTERNAL_PENDING && c->async_phase == ws_ctx::ASYNC_LAUNCHED) {
-    if ((rc = unions_and_relabel(true))) { c->async_phase = ws_ctx::ASYNC_NONE; c->tile_min_out = nullptr; return rc; }
+  if (half == 2 || (rc == WS_INTERNAL_PENDING && c->async_phase == ws_ctx::ASYNC_LAUNCHED)) {
+    if (half != 2 && (rc = unions_and_relabel(true))) { c->async_phase = ws_ctx::ASYNC_NONE; c->tile_min_out = nullptr; return rc; }
     speculated = true;
+    if (half == 1) return WS_INTERNAL_PENDING;      // (the context stays ASYNC_LAUNCHED, tile_min_out set: ws_merge_device_end)
     c->async_phase = ws_ctx::ASYNC_RESUME;      // the host half: waits for the graph's end event, reads its words, goes on if it must
     rc = run_fused(c, src, src_stride, (int)ph, (int)pw, opt->max_water_level, seeds, n_seeds, seg, padded);
   }
@@ -1669,6 +1675,40 @@ int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t 
   if (!(speculated && c->graph_sufficed) && (rc = unions_and_relabel(c->tile_min_filled))) return rc;
   c->stats.merge_levels = 1;
   return stats_end(c);
+}
+
+int ws_merge_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                    size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "a transform begun with ws_*_device_begin has not been ended");
+  return merge_device_body(c, d_img, h, w, stride, d_seeds_rc, n_seeds, opt, d_labels, 0);
+}
+
+// ws_merge_device in two halves, as ws_segment_device_begin / _end: what is left in flight is the replayed graph of the
+// segmenting part AND the unions and the relabel queued behind it (see merge_device_body).
+int ws_merge_device_begin(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const uint32_t *d_seeds_rc,
+                          size_t n_seeds, const ws_options *opt, uint32_t *d_labels) {
+  if (!c || !opt) return WS_ERR_BAD_ARG;
+  if (c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "ws_merge_device_begin: the previous transform has not been ended");
+  c->async_args = {d_img, h, w, stride, d_seeds_rc, n_seeds, *opt, d_labels};
+  c->async_merge = true;
+  const int rc = merge_device_body(c, d_img, h, w, stride, d_seeds_rc, n_seeds, opt, d_labels, 1);
+  if (rc == WS_INTERNAL_PENDING && c->async_phase == ws_ctx::ASYNC_LAUNCHED) return WS_OK;
+  c->async_phase = ws_ctx::ASYNC_DONE;      // ran whole (or failed): _end hands the status over
+  c->async_rc = rc == WS_INTERNAL_PENDING ? (int)WS_ERR_UNSUPPORTED : rc;
+  return WS_OK;
+}
+
+int ws_merge_device_end(ws_ctx *c) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (!c->async_merge) return fail(c, WS_ERR_BAD_ARG, "ws_merge_device_end without ws_merge_device_begin");
+  if (c->async_phase == ws_ctx::ASYNC_DONE) { c->async_phase = ws_ctx::ASYNC_NONE; c->async_merge = false; return c->async_rc; }
+  if (c->async_phase != ws_ctx::ASYNC_LAUNCHED) return fail(c, WS_ERR_BAD_ARG, "ws_merge_device_end without ws_merge_device_begin");
+  const auto a = c->async_args;
+  const int rc = merge_device_body(c, a.d_img, a.h, a.w, a.stride, a.d_seeds, a.n_seeds, &a.opt, a.d_labels, 2);
+  c->async_phase = ws_ctx::ASYNC_NONE;
+  c->async_merge = false;
+  return rc == WS_INTERNAL_PENDING ? (int)WS_ERR_UNSUPPORTED : rc;
 }
 
 int ws_merge_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,

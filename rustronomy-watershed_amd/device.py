@@ -110,6 +110,24 @@ class DeviceEngine:
                                                   out.data_ptr()))
         return out
 
+    def merge_begin(self, img, seeds, out, max_level=254, edge=False, seed_shift=False):
+        """First half of merge() (ws_merge_device_begin); rules as segment_begin()."""
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        assert out.dtype == torch.int32 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == self._plane(img, edge)
+        h, w = img.shape
+        opt = self.options(max_level, edge, None, seed_shift)
+        ns = seeds.shape[0] if seeds.dim() == 2 else 0
+        self._pending = (img, seeds, out)
+        self.ctx.check(_ffi.lib().ws_merge_device_begin(self.ctx.handle, img.data_ptr(), h, w, w,
+                                                        seeds.data_ptr() if ns else None, ns, ctypes.byref(opt),
+                                                        out.data_ptr()))
+        return out
+
+    def merge_end(self):
+        pending, self._pending = getattr(self, "_pending", None), None
+        self.ctx.check(_ffi.lib().ws_merge_device_end(self.ctx.handle))
+        return pending[2] if pending else None
+
     def last_arrival(self):
         """Arrival stamps (level << 24 | ring) of the last fused-engine call, as a tensor copy."""
         p = ctypes.c_void_p()

@@ -737,3 +737,30 @@ def _pipelined_begin_end(pkg, dev, torch, mode):
         engines[0].segment(img, seeds, out=outs[0])
     engines[0].segment_end()
     assert (engines[0].segment(img, seeds, out=outs[0]).cpu().numpy().view(np.uint32) == want).all()
+    # the merging transform in two halves: the replayed graph and the unions queued behind it are left in flight; a flood
+    # that needs more passes than the graph holds (the smooth field) has its unions redone inside merge_end
+    if mode == "concurrent":
+        for himg in (cases.field(300, 772, 6), cases.smooth_field(520, 1028, 32, octaves=5)):
+            hseeds = ol.find_local_minima(himg)
+            want = ol.merge_arrival(himg, hseeds)
+            img = torch.from_numpy(himg).to(engines[0].device)
+            seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(engines[0].device).contiguous()
+            outs = [torch.zeros(himg.shape, dtype=torch.int32, device=engines[0].device) for _ in engines]
+            torch.cuda.synchronize()
+            pending = [False, False]
+            for k in range(10):
+                i = k & 1
+                if pending[i]:
+                    engines[i].merge_end()
+                    assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), (k, himg.shape)
+                    outs[i].zero_()
+                    torch.cuda.synchronize()
+                engines[i].merge_begin(img, seeds, outs[i])
+                pending[i] = True
+            for i in (0, 1):
+                engines[i].merge_end()
+                assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), ("tail", i)
+        engines[0].merge_begin(img, seeds, outs[0])
+        with pytest.raises(pkg.WatershedError):
+            engines[0].segment_end()              # the wrong end
+        engines[0].merge_end()
