@@ -727,6 +727,25 @@ def _pipelined_begin_end(pkg, dev, torch, mode):
             engines[i].segment_end()
             assert (outs[i].cpu().numpy().view(np.uint32) == want).all(), ("tail", i)
         assert replayed >= 4        # from its third call on an engine replays its graph: those were left in flight
+    # the CONTENTS of a replayed call's buffers are free to change: a list that is no longer sorted (the graph's tables are
+    # then invalid: _end repeats the transform with painted seeds) and a seed outside the plane (_end reports it)
+    perm = np.random.default_rng(3).permutation(len(hseeds))
+    seeds.copy_(torch.from_numpy(hseeds[perm].astype(np.int64)).to(torch.int32))
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        engines[i].segment_begin(img, seeds, outs[i])
+    for i in (0, 1):
+        engines[i].segment_end()
+        assert (outs[i].cpu().numpy().view(np.uint32) == ol.segment_arrival(himg, hseeds[perm])).all(), ("permuted", i)
+    bad = hseeds.copy()
+    bad[len(bad) // 2] = (himg.shape[0] + 5, 1)
+    seeds.copy_(torch.from_numpy(bad.astype(np.int64)).to(torch.int32))
+    torch.cuda.synchronize()
+    engines[0].segment_begin(img, seeds, outs[0])
+    with pytest.raises(pkg.SeedOutOfBounds):
+        engines[0].segment_end()
+    seeds.copy_(torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32))
+    torch.cuda.synchronize()
     # misuse
     with pytest.raises(pkg.WatershedError):
         engines[0].segment_end()
