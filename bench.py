@@ -13,6 +13,10 @@ c5                  BASELINE config 5: one 32768x32768 field in row blocks over 
 
 A "step" is one pass of the whole hot path over the configuration's input (seed tables, all 255 water levels, final
 labels); image and seeds are resident in HBM before the timed region, u32 labels stay in HBM.
+headline and c3 keep `--contexts` (4) such steps in flight: engine contexts on streams of their own take turns
+(ws_segment_device_begin / _end), so that a step is queued before the one ahead of it has been waited for and steps of
+different contexts overlap on the GPU.  `value` is the throughput of that; the time of ONE transform with nothing else in
+flight is measured right after and reported as config.ms_one_transform_alone (`--no-pipeline`: only that form).
 
 Launch: under torchrun (RANK / WORLD_SIZE in the environment) every process is one rank.  A plain
 `python bench.py --gpus N` with N > 1 starts its own N rank processes BEFORE touching a GPU.  When the ranks
