@@ -716,6 +716,12 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
 
 extern "C" {
 
+// a context that holds a transform begun with ws_*_device_begin takes no other work until the matching _end
+static int refuse_if_in_flight(ws_ctx *c) {
+  if (c && c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "the context holds a transform begun with ws_*_device_begin: end it first");
+  return WS_OK;
+}
+
 int ws_abi_version(void) { return WS_ABI_VERSION; }
 
 const char *ws_strerror(int status) {
@@ -844,6 +850,7 @@ int ws_ctx_synchronize(ws_ctx *c) {
 
 int ws_find_local_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride,
                                 uint32_t *d_out_rc, size_t cap, size_t *n_found) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || !n_found || (!d_img && h * w) || (!d_out_rc && cap)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
   if (stride < w) return fail(c, WS_ERR_BAD_ARG, "row_stride < w");
   if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^32 pixels");
@@ -869,6 +876,7 @@ int ws_find_local_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_
 
 int ws_find_local_minima(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, uint64_t *out_rc,
                          size_t cap, size_t *n_found) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || !n_found || (!img && h * w) || (!out_rc && cap)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
   if (stride < w) return fail(c, WS_ERR_BAD_ARG, "row_stride < w");
   *n_found = 0;
@@ -897,12 +905,14 @@ int ws_find_local_minima(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size
 
 int ws_segment(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                size_t n_seeds, const ws_options *opt, uint64_t *out_labels) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!out_labels) return fail(c, WS_ERR_BAD_ARG, "out_labels is null");
   return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, out_labels);
 }
 
 int ws_segment_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                          size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels);
 }
 
@@ -971,6 +981,7 @@ int ws_segment_device_end(ws_ctx *c) {
 }
 
 int ws_last_arrival_device(ws_ctx *c, const uint32_t **d_keys, size_t *h, size_t *w) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || !d_keys || !h || !w) return WS_ERR_BAD_ARG;
   if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call did not use the fused engine");
   *d_keys = (const uint32_t *)c->keys.p;
@@ -980,6 +991,7 @@ int ws_last_arrival_device(ws_ctx *c, const uint32_t **d_keys, size_t *h, size_t
 }
 
 int ws_copy_last_arrival_device(ws_ctx *c, uint32_t *d_dst, size_t n_elems) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || !d_dst) return WS_ERR_BAD_ARG;
   if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call did not use the fused engine");
   const size_t n = c->last_h * c->last_w;
@@ -990,6 +1002,7 @@ int ws_copy_last_arrival_device(ws_ctx *c, uint32_t *d_dst, size_t n_elems) {
 }
 
 int ws_level_snapshot_device(ws_ctx *c, const uint32_t *d_labels, uint8_t water_level, uint32_t *d_out) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || !d_labels || !d_out) return fail(c, WS_ERR_BAD_ARG, "null pointer");
   if (!c->have_keys) return fail(c, WS_ERR_UNSUPPORTED, "no arrival stamps: the last call was not a fused-engine ws_segment_device / ws_merge_device");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -998,6 +1011,7 @@ int ws_level_snapshot_device(ws_ctx *c, const uint32_t *d_labels, uint8_t water_
 }
 
 int ws_random_field_device(ws_ctx *c, uint8_t *d_img, size_t h, size_t w, size_t stride, uint64_t seed) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || (!d_img && h * w) || stride < w) return fail(c, WS_ERR_BAD_ARG, "bad argument");
   if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull) return fail(c, WS_ERR_TOO_LARGE, "too large");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1017,6 +1031,7 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out) {
 // ---- pre-processor (lib.rs:1081-1173) --------------------------------------------------------------
 
 int ws_pre_processor_device(ws_ctx *c, const void *d_data, int dtype, size_t n, uint8_t max_value, uint8_t *d_out) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c || (n && (!d_data || !d_out))) return fail(c, WS_ERR_BAD_ARG, "null pointer");
   if (preproc_elem_size(dtype) == 0) return fail(c, WS_ERR_BAD_ARG, "unknown dtype");
   if (max_value >= WS_NEVER_FILL) return fail(c, WS_ERR_MAX_TOO_HIGH, "MAX must be < NEVER_FILL (lib.rs:1143)");
@@ -1598,6 +1613,7 @@ static int segment_batch_stacked(ws_ctx *c, const uint8_t *d_cube, size_t n_slic
 int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, size_t h, size_t w, size_t stride,
                             size_t slice_stride, const uint32_t *d_seeds_rc, const size_t *seed_offsets,
                             const ws_options *opt, uint32_t *d_labels, size_t *failed_slice) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c) return WS_ERR_BAD_ARG;
   if (failed_slice) *failed_slice = 0;
   if (n_slices && (!seed_offsets || !opt)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
@@ -1713,12 +1729,14 @@ int ws_merge_device_end(ws_ctx *c) {
 
 int ws_merge_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                        size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   return merge_host(c, true, img, h, w, stride, seeds_rc, n_seeds, opt, cb, user, out_labels, nullptr, 0, nullptr, nullptr, nullptr);
 }
 
 int ws_transform_to_list_device(ws_ctx *c, int merging, const uint8_t *d_img, size_t h, size_t w, size_t stride,
                                 const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *d_lakes, size_t cap,
                                 size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!n_lakes || !offsets || !uncoloured || (!d_lakes && cap) || (!d_img && h * w) || (!d_seeds_rc && n_seeds))
     return fail(c, WS_ERR_BAD_ARG, "null pointer");
   const DeviceLists dev{d_img, d_seeds_rc, d_lakes};
@@ -1729,6 +1747,7 @@ int ws_transform_to_list_device(ws_ctx *c, int merging, const uint8_t *d_img, si
 int ws_transform_to_list(ws_ctx *c, int merging, const uint8_t *img, size_t h, size_t w, size_t stride,
                          const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *lakes, size_t cap,
                          size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!n_lakes || !offsets || !uncoloured || (!lakes && cap)) return fail(c, WS_ERR_BAD_ARG, "null output pointer");
   return merge_host(c, merging != 0, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, nullptr, lakes, cap, n_lakes,
                     offsets, uncoloured);

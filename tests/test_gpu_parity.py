@@ -754,6 +754,8 @@ def _pipelined_begin_end(pkg, dev, torch, mode):
         engines[0].segment_begin(img, seeds, outs[0])
     with pytest.raises(pkg.WatershedError):
         engines[0].segment(img, seeds, out=outs[0])
+    with pytest.raises(pkg.WatershedError):
+        engines[0].find_local_minima(img)         # any other work on a context that holds a transform
     engines[0].segment_end()
     assert (engines[0].segment(img, seeds, out=outs[0]).cpu().numpy().view(np.uint32) == want).all()
     # the merging transform in two halves: the replayed graph and the unions queued behind it are left in flight; a flood
