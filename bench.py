@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--engine", choices=["fused", "sweep"], default="fused")
     ap.add_argument("--cpu-size", type=int, default=4096, help="side of the CPU-baseline sample field (0 = skip)")
     ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the one CPU run of the bench field itself (~45 s at 8192^2)")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / cpu_baseline")
     ap.add_argument("--contexts", type=int, default=4, help="headline: engine contexts that take turns, each on its own stream (1: as --no-pipeline)")
     ap.add_argument("--one-stream", action="store_true", help="headline: all contexts on one stream (transforms queue up, never overlap)")
@@ -80,40 +81,47 @@ def spawn_ranks(n):
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------------
 
-def cpu_baseline(size, seed, runs):
+def cpu_baseline(size, seed, runs, full_size=0):
     """The oracle's rayon-shaped port (oracle/ws_oracle_par.c: parallel full-image scan -> sequential scatter, per
-    level, as lib.rs:1689-1748) on this host's cores; median of `runs` full transforms of a size x size sample."""
+    level, as lib.rs:1689-1748) on this host's cores; median of `runs` full transforms of a size x size sample, and
+    (full_size > size) ONE transform of the bench field itself beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    img = ol.random_field(size, size, seed)
-    seeds = ol.find_local_minima(img)
-    times, scans = [], 0
-    for _ in range(max(runs, 1)):
-        t0 = time.perf_counter()
-        _, st = ol.segment_par(img, seeds)
-        times.append(time.perf_counter() - t0)
-        scans = st.scans
-    times.sort()
+
+    def timed(side, n_runs):
+        img = ol.random_field(side, side, seed)
+        seeds = ol.find_local_minima(img)
+        times, scans = [], 0
+        for _ in range(max(n_runs, 1)):
+            t0 = time.perf_counter()
+            _, st = ol.segment_par(img, seeds)
+            times.append(time.perf_counter() - t0)
+            scans = st.scans
+        times.sort()
+        return times, scans
+    times, scans = timed(size, runs)
     med = times[len(times) // 2]
-    return {"value": round(size * size / med / 1e6, 4), "unit": "Mpixels/s", "cores": ol.max_threads(), "kind": "port",
-            "sample": f"{size}x{size} u8 field of the bench's generator (seed {seed}), full 255-level segmenting transform "
-                      f"({scans} full-image scans), median of {len(times)} runs; the bench field is 8192x8192 "
-                      f"(--cpu-size 8192 runs it whole: ~45 s per run)",
-            "seconds_per_run": [round(t, 2) for t in times]}
+    out = {"value": round(size * size / med / 1e6, 4), "unit": "Mpixels/s", "cores": ol.max_threads(), "kind": "port",
+           "sample": f"{size}x{size} u8 field of the bench's generator (seed {seed}), full 255-level segmenting transform "
+                     f"({scans} full-image scans), median of {len(times)} runs",
+           "seconds_per_run": [round(t, 2) for t in times]}
+    if full_size > size:
+        ft, fscans = timed(full_size, 1)
+        out["bench_field_run"] = {"value": round(full_size * full_size / ft[0] / 1e6, 4), "unit": "Mpixels/s", "seconds": round(ft[0], 2),
+                                  "sample": f"the bench field itself: {full_size}x{full_size}, seed {seed}, one full transform ({fscans} scans)"}
+    return out
 
 
 # ---- extras of the headline configuration -----------------------------------------------------------------------------
 
-def end_to_end(pkg, H, W, runs=5):
+def end_to_end(pkg, eng, H, W, runs=5):
     """ws_segment through the host ABI with reused, already touched host buffers: pageable u8 image and u64 seeds in,
     u64 labels out -- what a Rust caller of transform(ArrayView2<u8>, &seeds) (lib.rs:1810) sees.  Never `value`."""
     import ctypes
     import importlib
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as ol
     ffi = importlib.import_module("rustronomy_watershed_amd._ffi")
-    img = ol.random_field(H, W, 1)
+    img = eng.random_field(H, W, 1).cpu().numpy()      # the engine's generator (ws_random_field_device) and one D2H copy
     ws = pkg.TransformBuilder.default().build_segmenting()
     ctx, opt = ws._ctx(), ws._opt
     cap = (H // 2 + 1) * (W // 2 + 1)
@@ -218,7 +226,7 @@ def run(args):
     pipelined = False
     if cfg in ("headline", "c3"):
         H = W = args.size or 8192
-        img = eng.random_field(H, W, 1 + rank)          # one independent field per rank
+        img = eng.random_field(H, W, 1 + 16 * rank)     # independent fields per rank (and per context: below)
         seeds = eng.find_local_minima(img)
         labels = torch.empty((H, W), dtype=torch.int32, device=eng.device)
         n_seeds = int(seeds.shape[0])
@@ -235,25 +243,31 @@ def run(args):
             # chase) another one's kernels run.  Every step is still one whole transform of the same field into its
             # context's own label plane; a context's previous transform is waited for before its next one is queued.
             # (`--one-stream`: all contexts on one stream, so that transforms only queue up behind each other.)
-            pipe_engines, pipe_labels = [eng], [labels]
-            for _ in range(args.contexts - 1):
+            # EVERY context transforms a field and a seed list of its own (generator seeds 1 + 16 rank + i): the contexts'
+            # inputs are distinct buffers with distinct contents (4 x 120 MiB > the 256 MiB Infinity Cache), so that no
+            # transform re-reads what another one has just fetched.
+            pipe_engines, pipe_labels, pipe_imgs, pipe_seeds = [eng], [labels], [img], [seeds]
+            for i in range(1, args.contexts):
                 if args.one_stream:
                     pipe_engines.append(dev.DeviceEngine(dev_index, engine=pkg.ENGINE_FUSED))
                 else:
                     with torch.cuda.stream(torch.cuda.Stream(dev_index)):
                         pipe_engines.append(dev.DeviceEngine(dev_index, engine=pkg.ENGINE_FUSED))
                 pipe_labels.append(torch.empty_like(labels))
+                pipe_imgs.append(eng.random_field(H, W, 1 + 16 * rank + i))
+                pipe_seeds.append(eng.find_local_minima(pipe_imgs[i]).clone())
+            torch.cuda.synchronize()
             pipe = {"k": 0, "pending": [False] * args.contexts}
-            for e_, l_ in zip(pipe_engines, pipe_labels):      # third call on: the context replays its graph
+            for e_, l_, i_, s_ in zip(pipe_engines, pipe_labels, pipe_imgs, pipe_seeds):      # third call on: the context replays its graph
                 for _ in range(3):
-                    (e_.merge if merging else e_.segment)(img, seeds, out=l_)
+                    (e_.merge if merging else e_.segment)(i_, s_, out=l_)
             torch.cuda.synchronize()
 
             def step():
                 i = pipe["k"] % args.contexts
                 if pipe["pending"][i]:
                     (pipe_engines[i].merge_end if merging else pipe_engines[i].segment_end)()
-                (pipe_engines[i].merge_begin if merging else pipe_engines[i].segment_begin)(img, seeds, pipe_labels[i])
+                (pipe_engines[i].merge_begin if merging else pipe_engines[i].segment_begin)(pipe_imgs[i], pipe_seeds[i], pipe_labels[i])
                 pipe["pending"][i] = True
                 pipe["k"] += 1
 
@@ -265,7 +279,8 @@ def run(args):
                 pipe["k"] = 0
             pipelined = True
         workload = (f"{H}x{W} u8 uniform[0,254) random field per GPU, {'MERGING transform (final canonical labels)' if cfg == 'c3' else 'segmenting transform'}, max_water_level 254, "
-                    f"seeds = find_local_minima ({n_seeds} on rank 0), engine {args.engine}")
+                    f"seeds = find_local_minima ({n_seeds} on rank 0's first field), engine {args.engine}"
+                    + (f"; {args.contexts} contexts in flight, each transforming ITS OWN field and seed list (generator seeds 1..{args.contexts})" if pipelined else ""))
         parallelism = f"independent fields x{world}"
         units = {"fields_per_gpu": 1}
     elif cfg == "c4":
@@ -333,11 +348,14 @@ def run(args):
     replayed = bool(st_last.get("graph_launches", 0))      # of the last timed transform
     ms_one_context = None
     if pipelined:
-        # the same K steps on ONE context, every transform waited for before the next is queued (what a caller of the
-        # one-call form gets): reported beside the pipelined figure, never as `value`
+        # the same K steps with NOTHING else in flight: every transform is waited for before the next is queued (what a
+        # caller of the one-call form gets).  The transforms rotate over the contexts' fields (each context replays its own
+        # graph on its own buffers), so that a transform never finds its input in the Infinity Cache from the one before.
         def step():
-            (eng.merge if merging else eng.segment)(img, seeds, out=labels)
-        for _ in range(3):
+            i = pipe["k"] % args.contexts
+            (pipe_engines[i].merge if merging else pipe_engines[i].segment)(pipe_imgs[i], pipe_seeds[i], out=pipe_labels[i])
+            pipe["k"] += 1
+        for _ in range(2 * args.contexts):
             step()
         barrier()
         t1 = time.perf_counter()
@@ -345,6 +363,9 @@ def run(args):
             step()
         barrier()
         ms_one_context = (time.perf_counter() - t1) * 1e3 / args.steps
+
+        def step():      # the kernel leg below: context 0 on its own field
+            (eng.merge if merging else eng.segment)(img, seeds, out=labels)
     # ---- kernel leg: the same `steps` steps again with a HIP-event pair around every launch (recorded on the stream
     # the kernels run on) for the roofline object ----
     agg = {"ms_relax": 0.0, "ms_resolve": 0.0, "ms_sweep": 0.0, "ms_other": 0.0, "ms_total": 0.0, "launches_relax": 0,
@@ -423,7 +444,7 @@ def run(args):
             if cfg == "headline" and args.engine == "fused" and H == 8192 and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 roof["traffic"] = int(tj["k_relax"]["bytes_per_launch"])
-                roof["traffic_source"] = tj["source"]
+                roof["traffic_source"] = "SINGLE-CONTEXT profile (one transform at a time, not the timed mode with several in flight): " + tj["source"]
                 if "transform_total_bytes" in tj:
                     roof["traffic_total"] = int(tj["transform_total_bytes"])       # all kernels of one transform, PMC
                     roof["traffic_total_over_compulsory"] = round(tj["transform_total_bytes"] / b_min, 3)
@@ -456,7 +477,8 @@ def run(args):
                                                  "times_hbm_peak": round(sweep_equiv / HBM_PEAK_GBS, 3),
                                                  "note": "speed-equivalent of a sweep-per-level engine, not bandwidth"}
         out = {
-            "metric": "Mpixels/s segmenting watershed, 8192x8192 u8, device-resident" if cfg == "headline"
+            "metric": ("Mpixels/s segmenting watershed, 8192x8192 u8, device-resident"
+                       + (f" (throughput, {args.contexts} transforms of distinct fields in flight; one transform alone: value_one_transform_alone)" if pipelined else "")) if cfg == "headline"
                       else ("Mpixels/s merging watershed (final labels), 8192x8192 u8, BASELINE config c3, device-resident" if cfg == "c3"
                             else f"Mpixels/s segmenting watershed, BASELINE config {cfg}, device-resident"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -480,6 +502,9 @@ def run(args):
         if ms_one_context is not None:      # the time of ONE transform when nothing else is in flight (the one-call form)
             out["config"]["contexts_in_flight"] = args.contexts
             out["config"]["ms_one_transform_alone"] = round(ms_one_context, 4)
+            out["ms_one_transform_alone"] = round(ms_one_context, 4)
+            out["value_one_transform_alone"] = round(npx_rank * world / (ms_one_context * 1e-3) / 1e6, 2)
+            roof["frac_compulsory_one_transform_alone"] = round(b_min / (ms_one_context * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if labels is not None:
             out["config"]["coloured_px"] = int((labels != 0).sum().item())
         extras = cfg == "headline" and world == 1 and not args.no_extras
@@ -490,8 +515,8 @@ def run(args):
             out["secondary"]["other_correlation_lengths"] = {
                 str(c): {k: v for k, v in secondary_smooth(eng, torch, H, corr=c).items() if k in ("ms", "relax_passes")} for c in (4, 16, 256)}
             torch.cuda.empty_cache()
-            out["end_to_end"] = end_to_end(pkg, H, W)
-        out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1, args.cpu_runs) if (world == 1 and args.cpu_size > 0 and not args.no_extras) else None
+            out["end_to_end"] = end_to_end(pkg, eng, H, W)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1, args.cpu_runs, 0 if args.no_cpu_full or cfg != "headline" else H) if (world == 1 and args.cpu_size > 0 and not args.no_extras) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -38,7 +38,7 @@ constexpr int NTHREADS = 256;
 // Per-pass convergence words.  Workgroups never share an atomic: a tile that changed stores 1
 // (plain, idempotent) into the stripe blockIdx % NSTRIPE of the pass's slot; stripes sit on their
 // own 64-byte lines.  The host reads one slot (NSTRIPE lines) per pass.
-constexpr int COUNTER_RING = 64;                  // slots reused cyclically, one per pass (two groups of passes in flight: ws_api.hip)
+constexpr int COUNTER_RING = 64;                  // slots reused cyclically, one per pass (two groups of passes in flight: ws_ctx.hpp)
 constexpr int NSTRIPE = 64;
 constexpr int STRIPE_STRIDE = 16;                 // words between stripes (64 bytes)
 constexpr int FLAG_SLOT = NSTRIPE * STRIPE_STRIDE;   // words per slot

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   // some other list: nothing may be computed from them (the host repeats the transform once it has read the same words).
   // k_seed_tables has finished before this kernel starts, so the words are final: [0] out of bounds, [2] not strict.
   if (TABLES && seed_err && (seed_err[0] | seed_err[2]) != 0u) return;
-  // Speculative launch (ws_api.hip): queued behind a relaxation pass before the host knows whether that pass still
+  // Speculative launch (ws_segment.hip): queued behind a relaxation pass before the host knows whether that pass still
   // changed anything.  `gate` is the pass's striped convergence slot: any word set -> not a fixpoint yet, leave.
   if (gate && __builtin_amdgcn_ballot_w64(gate[(threadIdx.x & 63) * STRIPE_STRIDE] != 0u) != 0ull) return;
   const uint32_t tile = xcd_span_index(blockIdx.x, gridDim.x);

@@ -889,7 +889,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       pf.any_change[stripe] = 1u;
     }
     if (pf.stats) {            // profiling only: striped counters, one per 64-byte line
-      atomicAdd(&pf.stats[stripe], (uint32_t)(TW * TH / 2048));      // in quarter tiles: a 256 x 8 band is one, every other tile four (ws_api.hip divides)
+      atomicAdd(&pf.stats[stripe], (uint32_t)(TW * TH / 2048));      // in quarter tiles: a 256 x 8 band is one, every other tile four (ws_segment.hip divides)
       atomicAdd(&pf.stats[FLAG_SLOT + stripe], iters);
     }
   }

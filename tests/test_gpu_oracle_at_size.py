@@ -1,0 +1,106 @@
+"""The oracle at BASELINE sizes, inside the suite the driver runs.
+
+The other full-size tests prove the result by its defining equations on the device; these compare the HIP engine with
+the CPU oracle itself (`ws_or_segment_arrival` / `ws_or_merge_arrival`, the arrival-form restatements that
+tests/test_oracle_golden.py proves equal to the literal sweep restatement of lib.rs:1638-1808 / 1328-1522) on planes
+the oracle finishes in seconds to tens of seconds:
+
+  * segmenting: 4096^2 random, 3000 x 5000 smooth, 3071 x 4097 odd-sized random, and the 8192^2 headline field;
+  * merging final labels where lakes are NOT trivial: max_water_level 100 and 200 on 4096^2 (at 254 a random field is
+    one lake and an over-merging engine could not be told from a correct one);
+  * transform_to_list_device (records left in HBM) against the oracle's lake sizes at 2048^2 on five levels.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import cases
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    ge.build_hip()
+    return ge.load_package()
+
+
+def _engine():
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    return dev.DeviceEngine(0)
+
+
+def _device_segment(eng, img, seeds, merging=False, max_level=254):
+    import torch
+    d_img = torch.from_numpy(img).to(eng.device)
+    d_seeds = torch.from_numpy(np.ascontiguousarray(seeds, dtype=np.int64).astype(np.int32)).to(eng.device).reshape(-1, 2).contiguous()
+    out = (eng.merge if merging else eng.segment)(d_img, d_seeds, max_level=max_level)
+    return (out.to(torch.int64) & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.parametrize("name", ["rand4096", "smooth3000x5000", "rand_odd3071x4097"])
+def test_segmenting_equals_oracle_at_size(pkg, name):
+    img = {"rand4096": lambda: ol.random_field(4096, 4096, 9),
+           "smooth3000x5000": lambda: cases.smooth_field(3000, 5000, 4, octaves=7),
+           "rand_odd3071x4097": lambda: ol.random_field(3071, 4097, 5)}[name]()
+    seeds = ol.find_local_minima(img)
+    want = ol.segment_arrival(img, seeds)
+    got = _device_segment(_engine(), img, seeds)
+    assert got.shape == want.shape
+    bad = int((got != want).sum())
+    assert bad == 0, f"{name}: {bad} labels differ from the oracle"
+
+
+def test_headline_field_8192_equals_oracle(pkg):
+    # the bench field itself (bench.py: generator seed 1, seeds = find_local_minima), every label against the oracle
+    import torch
+    eng = _engine()
+    d_img = eng.random_field(8192, 8192, 1)
+    d_seeds = eng.find_local_minima(d_img)
+    out = eng.segment(d_img, d_seeds)
+    img = d_img.cpu().numpy()
+    assert (img == ol.random_field(8192, 8192, 1)).all()              # the engine's generator is the oracle's
+    seeds = ol.find_local_minima(img)
+    assert (d_seeds.cpu().numpy().astype(np.int64) == np.asarray(seeds, dtype=np.int64).reshape(-1, 2)).all()
+    want = ol.segment_arrival(img, seeds)
+    got = (out.to(torch.int64) & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+    bad = int((got != want).sum())
+    assert bad == 0, f"{bad} labels of the headline field differ from the oracle"
+
+
+@pytest.mark.parametrize("max_level", [100, 200])
+def test_merging_partial_levels_4096_equals_oracle(pkg, max_level):
+    # partly flooded: thousands of lakes of every size, one-lake tiles next to general ones, uncoloured pixels
+    img = ol.random_field(4096, 4096, 12)
+    seeds = ol.find_local_minima(img)
+    want = ol.merge_arrival(img, seeds, max_level=max_level)
+    got = _device_segment(_engine(), img, seeds, merging=True, max_level=max_level)
+    n_lakes = np.unique(want).size - 1
+    assert n_lakes > 1000, n_lakes                                    # the point of the test: lakes are not trivial here
+    bad = int((got != want).sum())
+    assert bad == 0, f"max_level {max_level}: {bad} labels differ from the oracle ({n_lakes} lakes)"
+
+
+def test_transform_to_list_device_2048_lake_sizes_equal_oracle(pkg):
+    import torch
+    levels = (0, 40, 128, 200, 254)
+    img = ol.random_field(2048, 2048, 21)
+    seeds = ol.find_local_minima(img)
+    want = {}
+    ol.merge_arrival(img, seeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)) if l in levels else None)
+    eng = _engine()
+    d_img = torch.from_numpy(img).to(eng.device)
+    d_seeds = torch.from_numpy(np.asarray(seeds, dtype=np.int64).astype(np.int32)).to(eng.device).reshape(-1, 2).contiguous()
+    lakes, offsets, unc = eng.transform_to_list(d_img, d_seeds, merging=True)
+    lakes = lakes.cpu().numpy()
+    assert offsets[0] == 0 and offsets[-1] == lakes.shape[0]
+    for lvl in levels:
+        rec = lakes[int(offsets[lvl]):int(offsets[lvl + 1])]
+        assert (np.diff(rec[:, 0]) > 0).all(), lvl                    # sorted by colour, every lake once
+        dense = np.zeros(2048 * 2048 + 1, np.uint64)                  # lib.rs:630: pixels + 1 entries, index 0 = uncoloured
+        dense[rec[:, 0]] = rec[:, 1].astype(np.uint64)
+        dense[0] = unc[lvl]
+        assert (dense == want[lvl]).all(), lvl
