@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 2 /* 2: ws_options grew to 8 bytes (seed_shift) */
+#define WS_ABI_VERSION 3 /* 2: ws_options grew to 8 bytes (seed_shift); 3: ws_group_* / ws_*_tiled / ws_segment_batch_group, WS_ERR_RCCL */
 
 /* lib.rs:138-141 */
 #define WS_UNCOLOURED 0u
@@ -72,7 +72,8 @@ typedef enum ws_status {
   WS_ERR_CAPACITY = -8,      /* output buffer too small; *n_found still holds the true count */
   WS_ERR_RING_OVERFLOW = -9, /* > 2^24-1 flood rings inside one level (needs > 16.7 M pixel corridor) */
   WS_ERR_TOO_LARGE = -10,    /* plane has >= 2^32 pixels or seeds */
-  WS_ERR_UNSUPPORTED = -11
+  WS_ERR_UNSUPPORTED = -11,
+  WS_ERR_RCCL = -12          /* an RCCL call failed, or librccl.so could not be loaded; see ws_group_last_error */
 } ws_status;
 
 typedef enum ws_engine {
@@ -192,8 +193,10 @@ int ws_merge_with_hook(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size
                        ws_level_cb cb, void *user, uint64_t *out_labels);
 
 /* Watershed::transform_to_list (lib.rs:1551-1561 merging, 1837-1847 segmenting), sparse:
- * for level l the lakes with area > 0 are lakes[offsets[l] .. offsets[l+1]), sorted by
- * colour; the uncoloured count (index 0 of the reference's vector) is uncoloured[l].
+ * for level l the lakes with area > 0 are lakes[offsets[l] .. offsets[l+1]), every lake
+ * once, as runs of increasing colours in no particular order of the runs (the reference's
+ * vector is indexed by colour, so a caller scatters them: hist[colour] = area); the
+ * uncoloured count (index 0 of the reference's vector) is uncoloured[l].
  * offsets has max_water_level+2 entries, uncoloured max_water_level+1.
  * *n_lakes receives the total number of records; WS_ERR_CAPACITY if cap is too small. */
 int ws_transform_to_list(ws_ctx *ctx, int merging, const uint8_t *img, size_t h, size_t w,
@@ -333,6 +336,83 @@ int ws_block_merge_export(ws_ctx *ctx, const uint32_t *d_labels, size_t h, size_
 int ws_block_merge_import(ws_ctx *ctx, const uint32_t *d_pairs, size_t n_pairs, uint32_t *d_parent);
 int ws_block_merge_relabel(ws_ctx *ctx, const uint32_t *d_labels, size_t n, uint32_t *d_parent, size_t n_colours_total,
                            uint32_t *d_out);
+
+/* ---- several GPUs driven inside the library --------------------------------------------------------
+ *
+ * The reference's drivers are one address space and one rayon pool (lib.rs:1689-1748); a drop-in that wants the GPUs of a
+ * node behind the same transform() call cannot ask its caller to bring torch.distributed or MPI.  A ws_group is a set of
+ * RANKS, each with a context of its own on one device, plus the three exchange steps the tiled transform needs -- swap the
+ * halo rows with the neighbour ranks, max-reduce one word, all-gather a small table -- in one of two implementations:
+ *
+ *   local  all ranks live in THIS process (one host thread each while a call runs); rank r sits on devices[r].  The
+ *          exchange steps are stream-ordered copies between the ranks' buffers (peer-to-peer between devices).  A device
+ *          may appear more than once: ranks then share it -- the protocol rehearsed on a one-GPU box, and what the tests run.
+ *   rccl   THIS process is ONE rank of `world` (one process per GPU: torchrun / mpirun).  Halo rows travel as grouped
+ *          ncclSend / ncclRecv pairs, the flag word through ncclAllReduce(max), tables through ncclAllGather, all on the
+ *          rank's own stream, over xGMI.  librccl.so is loaded when the first such group is created.  Every rank passes the
+ *          same 128-byte id, made by ONE rank with ws_group_rccl_unique_id and handed to the others by whatever the job
+ *          already uses (MPI_Bcast, a file, torch.distributed.broadcast).
+ *
+ * Either way the transform is the single-domain one bit for bit (the arrival-stamp fixpoint is unique, DESIGN.md section
+ * 2 and 6): row blocks with one halo row per neighbour; stamps iterate (relax to local convergence, swap halo rows, stop
+ * when no rank received a row that differs from the one it held -- the difference is found on the device and reduced
+ * there, one host read per round); labels need one all-gather of the ranks' boundary rows (2 * w words per rank). */
+typedef struct ws_group ws_group;
+#define WS_RCCL_ID_BYTES 128
+
+int ws_group_create_local(int n_ranks, const int *devices /* n_ranks entries; NULL: every rank on device 0 */, ws_group **out);
+int ws_group_rccl_unique_id(void *id /* WS_RCCL_ID_BYTES */);
+int ws_group_create_rccl(int device, int rank, int world, const void *id /* WS_RCCL_ID_BYTES */, ws_group **out);
+void ws_group_destroy(ws_group *g);
+/* world: ranks of the whole group; n_local: ranks driven by this process (local: all; rccl: 1); first_local: the first of them */
+int ws_group_info(const ws_group *g, int *world, int *n_local, int *first_local);
+const char *ws_group_last_error(const ws_group *g);
+/* Runs every exchange step of the group once on small buffers and checks the results (WS_OK, or WS_ERR_RCCL / WS_ERR_HIP):
+ * a deployment check that the transport works before a field is committed to it.  Collective: every rank calls it. */
+int ws_group_selftest(ws_group *g);
+
+/* Rows of a field of `h` rows that rank `rank` of `world` OWNS: [*r0, *r1); its local plane is rows [*lo, *hi) = the same
+ * plus one halo row on every side that has a neighbour.  WS_ERR_BAD_ARG when h < world (every rank must own a row). */
+int ws_tile_rows(size_t h, int rank, int world, size_t *r0, size_t *r1, size_t *lo, size_t *hi);
+
+/* One field tiled over the ranks of a group, host buffers in and out -- what a caller of transform(ArrayView2<u8>, &seeds)
+ * (lib.rs:1810) has.  Every rank of the group calls it with the SAME arguments (local: one call drives all ranks); rank r
+ * uploads its rows of the image, takes its part of the seed list (any list: one that is not strictly increasing, or a
+ * width that is not a multiple of 4, takes the general form -- painted seeds, iterative label rounds -- on all ranks
+ * together), and writes the rows it owns of out_labels -- for a local group that is all of them.  merging != 0: the
+ * MERGING transform's final canonical labels (lib.rs:1328-1522 after the last level).  Edge correction pads the field
+ * first, as the reference does (lib.rs:1640-1666): out_labels is (h + 2) x (w + 2) then.  *exchange_rounds (nullable):
+ * collective steps of the call. */
+int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t row_stride, const uint64_t *seeds_rc,
+                     size_t n_seeds, const ws_options *opt, int merging, uint64_t *out_labels, uint32_t *exchange_rounds);
+
+/* The same with everything resident in HBM: one descriptor per LOCAL rank (ws_group_info), in rank order. */
+typedef struct ws_tile_block {
+  const uint8_t *d_img;        /* the rank's local plane: rows [lo, hi) of the field (ws_tile_rows), row stride w, on the rank's device */
+  const uint32_t *d_seeds_rc;  /* the seeds that fall on ANY local row, halo rows included, in LOCAL coordinates (row - lo, col) */
+  const uint32_t *d_colours;   /* their colours (index in the caller's list + 1, lib.rs:1670-1672); NULL: first_colour, first_colour + 1, ...
+                                  -- a contiguous range of a strictly increasing list, which is what the fast form needs */
+  size_t n_seeds;
+  uint32_t first_colour;
+  uint32_t reserved;           /* must be zero */
+  uint32_t *d_labels;          /* out: the local plane's labels, (hi - lo) x w u32; rows 0 / last are halo rows where the rank has neighbours */
+} ws_tile_block;
+int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seeds_total, const ws_tile_block *blocks,
+                            const ws_options *opt /* edge_correction must be 0: pad the field first */, int merging,
+                            uint32_t *exchange_rounds);
+
+/* BASELINE config C4 over a group: a batch of independent slices, slice i on rank i % world, a rank's slices as ONE stacked
+ * transform (ws_segment_batch_device) -- no exchange step at all.  One descriptor per LOCAL rank: the rank's own slices,
+ * contiguous in its HBM.  Local groups run their ranks side by side (a host thread each). */
+typedef struct ws_batch_part {
+  const uint8_t *d_cube;         /* n_slices slices of h x w, contiguous (slice stride h * w), on the rank's device */
+  const uint32_t *d_seeds_rc;    /* all of its slices' (row, col) pairs, concatenated */
+  const size_t *seed_offsets;    /* n_slices + 1 entries, on the HOST */
+  size_t n_slices;
+  uint32_t *d_labels;            /* n_slices planes */
+} ws_batch_part;
+int ws_segment_batch_group(ws_group *g, size_t h, size_t w, const ws_batch_part *parts, const ws_options *opt,
+                           size_t *failed_rank, size_t *failed_slice);
 
 /* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
 int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,

@@ -1,9 +1,9 @@
-//! extern "C" declarations of include/ws_hip.h (ABI version 2), one to one.
+//! extern "C" declarations of include/ws_hip.h (ABI version 3), one to one.
 //! tests/test_abi_cpu.py checks that no function of the header is missing here.
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const WS_ABI_VERSION: c_int = 2;
+pub const WS_ABI_VERSION: c_int = 3;
 
 #[repr(C)]
 pub struct ws_ctx {
@@ -51,6 +51,36 @@ pub struct ws_stats {
     pub graph_launches: u32,
 }
 
+/// A set of ranks (one context and one device each) that transform one field, or one batch, together.
+#[repr(C)]
+pub struct ws_group {
+    _private: [u8; 0],
+}
+
+/// One rank's row block of a tiled field, device resident (ws_segment_tiled_device).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ws_tile_block {
+    pub d_img: *const u8,
+    pub d_seeds_rc: *const u32,
+    pub d_colours: *const u32,
+    pub n_seeds: usize,
+    pub first_colour: u32,
+    pub reserved: u32,
+    pub d_labels: *mut u32,
+}
+
+/// One rank's slices of a batch, device resident (ws_segment_batch_group); seed_offsets lives on the host.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ws_batch_part {
+    pub d_cube: *const u8,
+    pub d_seeds_rc: *const u32,
+    pub seed_offsets: *const usize,
+    pub n_slices: usize,
+    pub d_labels: *mut u32,
+}
+
 pub type ws_level_cb = Option<
     unsafe extern "C" fn(
         user: *mut c_void,
@@ -75,6 +105,8 @@ pub const WS_ERR_CAPACITY: c_int = -8;
 pub const WS_ERR_RING_OVERFLOW: c_int = -9;
 pub const WS_ERR_TOO_LARGE: c_int = -10;
 pub const WS_ERR_UNSUPPORTED: c_int = -11;
+pub const WS_ERR_RCCL: c_int = -12;
+pub const WS_RCCL_ID_BYTES: usize = 128;
 
 /// ws_dtype
 pub const WS_F32: c_int = 0;
@@ -171,4 +203,20 @@ extern "C" {
     pub fn ws_block_merge_import(ctx: *mut ws_ctx, d_pairs: *const u32, n_pairs: usize, d_parent: *mut u32) -> c_int;
     pub fn ws_block_merge_relabel(ctx: *mut ws_ctx, d_labels: *const u32, n: usize, d_parent: *mut u32,
         n_colours_total: usize, d_out: *mut u32) -> c_int;
+
+    // ---- several GPUs driven inside the library: local groups (all ranks in this process) and RCCL groups (one rank per process)
+    pub fn ws_group_create_local(n_ranks: c_int, devices: *const c_int, out: *mut *mut ws_group) -> c_int;
+    pub fn ws_group_rccl_unique_id(id: *mut c_void) -> c_int;
+    pub fn ws_group_create_rccl(device: c_int, rank: c_int, world: c_int, id: *const c_void, out: *mut *mut ws_group) -> c_int;
+    pub fn ws_group_destroy(g: *mut ws_group);
+    pub fn ws_group_info(g: *const ws_group, world: *mut c_int, n_local: *mut c_int, first_local: *mut c_int) -> c_int;
+    pub fn ws_group_last_error(g: *const ws_group) -> *const c_char;
+    pub fn ws_group_selftest(g: *mut ws_group) -> c_int;
+    pub fn ws_tile_rows(h: usize, rank: c_int, world: c_int, r0: *mut usize, r1: *mut usize, lo: *mut usize, hi: *mut usize) -> c_int;
+    pub fn ws_segment_tiled(g: *mut ws_group, img: *const u8, h: usize, w: usize, row_stride: usize, seeds_rc: *const u64,
+        n_seeds: usize, opt: *const ws_options, merging: c_int, out_labels: *mut u64, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_segment_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block,
+        opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_segment_batch_group(g: *mut ws_group, h: usize, w: usize, parts: *const ws_batch_part, opt: *const ws_options,
+        failed_rank: *mut usize, failed_slice: *mut usize) -> c_int;
 }

@@ -29,12 +29,14 @@ WS_ERR_CAPACITY = -8
 WS_ERR_RING_OVERFLOW = -9
 WS_ERR_TOO_LARGE = -10
 WS_ERR_UNSUPPORTED = -11
+WS_ERR_RCCL = -12
+WS_RCCL_ID_BYTES = 128
 
 WS_ENGINE_AUTO, WS_ENGINE_FUSED, WS_ENGINE_SWEEP = 0, 1, 2
 WS_DTYPES = {"float32": 0, "float64": 1, "int32": 2, "uint16": 3, "int16": 4, "uint8": 5}
 
 
-WS_ABI_VERSION = 2
+WS_ABI_VERSION = 3
 
 
 class Options(ctypes.Structure):
@@ -63,6 +65,17 @@ class Stats(ctypes.Structure):
 
 class Lake(ctypes.Structure):
     _fields_ = [("colour", ctypes.c_uint64), ("area", ctypes.c_uint64)]
+
+
+class TileBlock(ctypes.Structure):
+    """ws_tile_block: one rank's row block of a tiled field, device resident."""
+    _fields_ = [("d_img", vp), ("d_seeds_rc", vp), ("d_colours", vp), ("n_seeds", sz),
+                ("first_colour", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("d_labels", vp)]
+
+
+class BatchPart(ctypes.Structure):
+    """ws_batch_part: one rank's slices of a batch, device resident (seed_offsets on the host)."""
+    _fields_ = [("d_cube", vp), ("d_seeds_rc", vp), ("seed_offsets", szp), ("n_slices", sz), ("d_labels", vp)]
 
 
 LEVEL_CB = ctypes.CFUNCTYPE(None, vp, ctypes.c_uint8, ctypes.c_uint8, u8p, u64p, sz, sz)
@@ -118,6 +131,17 @@ SIGNATURES = {
     "ws_block_merge_import": (ctypes.c_int, [vp, vp, sz, vp]),
     "ws_block_merge_relabel": (ctypes.c_int, [vp, vp, sz, vp, sz, vp]),
     "ws_random_field_device": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint64]),
+    "ws_group_create_local": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]),
+    "ws_group_rccl_unique_id": (ctypes.c_int, [vp]),
+    "ws_group_create_rccl": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]),
+    "ws_group_destroy": (None, [vp]),
+    "ws_group_info": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ws_group_last_error": (ctypes.c_char_p, [vp]),
+    "ws_group_selftest": (ctypes.c_int, [vp]),
+    "ws_tile_rows": (ctypes.c_int, [sz, ctypes.c_int, ctypes.c_int, szp, szp, szp, szp]),
+    "ws_segment_tiled": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, vp, u32p]),
+    "ws_segment_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, ctypes.POINTER(TileBlock), ctypes.POINTER(Options), ctypes.c_int, u32p]),
+    "ws_segment_batch_group": (ctypes.c_int, [vp, sz, sz, ctypes.POINTER(BatchPart), ctypes.POINTER(Options), szp, szp]),
 }
 
 _lib = None

@@ -47,7 +47,32 @@ __global__ void k_fill_halo_rows(const uint32_t *__restrict__ resolved, uint32_t
   if (halo_flags & 1) labels[x] = resolved[((size_t)(rank - 1) * 2 + 1) * w + x];
   if (halo_flags & 2) labels[(size_t)(h - 1) * w + x] = resolved[((size_t)(rank + 1) * 2 + 0) * w + x];
 }
+// "some word of a[0 .. n) differs from b[0 .. n)": raises *flag (never clears it).  The halo rows a rank received against
+// the ones it holds -- the exchange loop's stop test, left on the device so that it can be max-reduced there.
+__global__ void k_rows_differ(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n, uint32_t *flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool d = i < n && a[i] != b[i];
+  if (__builtin_amdgcn_ballot_w64(d) != 0ull && (threadIdx.x & 63) == 0) *flag = 1u;
+}
 }  // namespace
+
+__global__ void k_iota(uint32_t *p, size_t n, uint32_t first) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = first + (uint32_t)i;
+}
+
+// p[i] = first + i: the colours of a contiguous range of the caller's seed list (ws_block_init wants them spelt out)
+hipError_t block_iota(hipStream_t s, uint32_t *p, size_t n, uint32_t first) {
+  if (n == 0) return hipSuccess;
+  k_iota<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, n, first);
+  return hipGetLastError();
+}
+
+hipError_t block_rows_differ(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *flag) {
+  if (n == 0) return hipSuccess;
+  k_rows_differ<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a, b, n, flag);
+  return hipGetLastError();
+}
 
 hipError_t block_export_boundary(hipStream_t s, const uint32_t *labels, int h, int w, int halo_flags, uint32_t rank, uint32_t *rows) {
   if (w == 0 || h == 0) return hipSuccess;

@@ -150,6 +150,8 @@ hipError_t block_flag_border_tiles(hipStream_t s, uint32_t *stamps, int h, int w
 hipError_t block_export_boundary(hipStream_t s, const uint32_t *labels, int h, int w, int halo_flags, uint32_t rank, uint32_t *rows);
 hipError_t block_import_boundary(hipStream_t s, const uint32_t *table, uint32_t world, uint32_t rank, uint32_t *resolved,
                                  uint32_t *labels, int h, int w, int halo_flags);
+hipError_t block_iota(hipStream_t s, uint32_t *p, size_t n, uint32_t first);      // p[i] = first + i
+hipError_t block_rows_differ(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *flag);      // raises *flag, never clears it
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded = false);

@@ -174,6 +174,7 @@ const char *ws_strerror(int status) {
     case WS_ERR_RING_OVERFLOW: return "ring counter overflow";
     case WS_ERR_TOO_LARGE: return "input too large";
     case WS_ERR_UNSUPPORTED: return "unsupported";
+    case WS_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
   }
 }

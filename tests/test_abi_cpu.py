@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(pkg):
     raw = ctypes.CDLL(pkg._ffi.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert pkg._ffi.lib().ws_abi_version() == pkg._ffi.WS_ABI_VERSION == 2
+    assert pkg._ffi.lib().ws_abi_version() == pkg._ffi.WS_ABI_VERSION == 3
 
 
 def test_options_default_and_validation(pkg):

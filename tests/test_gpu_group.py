@@ -1,0 +1,267 @@
+"""Several ranks behind one C call: ws_group_* / ws_segment_tiled(_device) / ws_segment_batch_group (csrc/ws_tiled.hip).
+
+The box has ONE GPU, so the LOCAL groups here put 2-4 ranks on device 0 (the protocol is the same: a host thread and a
+context per rank, the exchange steps as stream-ordered copies); the RCCL group runs with world == 1, which still sends the
+flag word through ncclAllReduce and the tables through ncclAllGather of the real library.  Every result is compared with
+the single-domain transform of the same inputs (itself oracle-checked in the other files) and, at small sizes, with the
+oracle directly.  Reference seam: the one-address-space loop of lib.rs:1689-1748.
+"""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import cases
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    ge.build_hip()
+    return ge.load_package()
+
+
+class Group:
+    def __init__(self, pkg, n_ranks=None, rccl=False):
+        self.ffi = pkg._ffi
+        self.L = self.ffi.lib()
+        self.h = ctypes.c_void_p()
+        if rccl:
+            uid = ctypes.create_string_buffer(self.ffi.WS_RCCL_ID_BYTES)
+            rc = self.L.ws_group_rccl_unique_id(uid)
+            assert rc == 0, (rc, self.L.ws_group_last_error(None))
+            rc = self.L.ws_group_create_rccl(0, 0, 1, uid, ctypes.byref(self.h))
+        else:
+            rc = self.L.ws_group_create_local(n_ranks, None, ctypes.byref(self.h))
+        assert rc == 0, (rc, self.L.ws_group_last_error(None))
+
+    def err(self):
+        return self.L.ws_group_last_error(self.h).decode()
+
+    def info(self):
+        w, n, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert self.L.ws_group_info(self.h, ctypes.byref(w), ctypes.byref(n), ctypes.byref(f)) == 0
+        return w.value, n.value, f.value
+
+    def segment_tiled(self, img, seeds, merging=False, max_level=254, edge=False, seed_shift=False, expect=0):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(-1, 2))
+        h, w = img.shape
+        e = 2 if edge else 0
+        out = np.zeros((h + e, w + e), dtype=np.uint64)
+        opt = self.ffi.Options(max_level, int(edge), 0, 0, int(seed_shift))
+        rounds = ctypes.c_uint32(0)
+        rc = self.L.ws_segment_tiled(self.h, img.ctypes.data, h, w, w, s.ctypes.data if s.size else None, s.shape[0], ctypes.byref(opt),
+                                     int(merging), out.ctypes.data, ctypes.byref(rounds))
+        assert rc == expect, (rc, self.err())
+        return out, rounds.value
+
+    def close(self):
+        if self.h:
+            self.L.ws_group_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+
+def test_tile_rows_partition_matches_distributed_py(pkg):
+    L = pkg._ffi.lib()
+    wsd = importlib.import_module("rustronomy_watershed_amd.distributed")
+    for h, world in ((10, 3), (8192, 8), (7, 7), (4097, 4), (32768, 8)):
+        for rank in range(world):
+            v = [ctypes.c_size_t() for _ in range(4)]
+            assert L.ws_tile_rows(h, rank, world, *[ctypes.byref(x) for x in v]) == 0
+            assert tuple(x.value for x in v) == wsd.row_block(h, rank, world)
+    v = [ctypes.c_size_t() for _ in range(4)]
+    assert L.ws_tile_rows(3, 0, 4, *[ctypes.byref(x) for x in v]) == pkg._ffi.WS_ERR_BAD_ARG      # a rank without rows
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 4])
+def test_local_group_selftest_and_info(pkg, n_ranks):
+    g = Group(pkg, n_ranks)
+    assert g.info() == (n_ranks, n_ranks, 0)
+    assert g.L.ws_group_selftest(g.h) == 0, g.err()
+    g.close()
+
+
+def test_rccl_group_of_one_rank_runs_the_real_library(pkg):
+    g = Group(pkg, rccl=True)
+    assert g.info() == (1, 1, 0)
+    assert g.L.ws_group_selftest(g.h) == 0, g.err()          # ncclAllReduce (max, min) and ncclAllGather with world == 1
+    img = cases.field(96, 128, 5)
+    seeds = ol.find_local_minima(img)
+    got, _ = g.segment_tiled(img, seeds)
+    assert (got == ol.segment(img, seeds)).all()
+    g.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 4])
+@pytest.mark.parametrize("shape", [(256, 512), (131, 260), (1000, 1024), (97, 100)])
+def test_tiled_host_equals_oracle_segmenting_and_merging(pkg, n_ranks, shape):
+    # widths that are multiples of 4 take the fast form (seed tables, one table exchange); 97 x 100 ... also; (131, 260) too;
+    # the general form is covered below (odd width, unsorted lists)
+    img = cases.field(shape[0], shape[1], 17 + n_ranks)
+    seeds = ol.find_local_minima(img)
+    g = Group(pkg, n_ranks)
+    got, rounds = g.segment_tiled(img, seeds)
+    assert (got == ol.segment_arrival(img, seeds)).all()
+    assert rounds >= 3                                   # the vote, at least one halo swap, the table
+    gotm, _ = g.segment_tiled(img, seeds, merging=True, max_level=120)
+    assert (gotm == ol.merge_arrival(img, seeds, max_level=120)).all()
+    g.close()
+
+
+def test_tiled_smooth_field_floods_cross_several_blocks(pkg):
+    # few seeds, long floods: chains cross the seams many times and in both directions
+    img = cases.smooth_field(600, 512, 3, octaves=5)
+    seeds = ol.find_local_minima(img)
+    g = Group(pkg, 4)
+    got, rounds = g.segment_tiled(img, seeds)
+    assert (got == ol.segment_arrival(img, seeds)).all()
+    gotm, _ = g.segment_tiled(img, seeds, merging=True)
+    assert (gotm == ol.merge_arrival(img, seeds)).all()
+    g.close()
+
+
+def test_tiled_general_form_odd_width_unsorted_and_duplicate_seeds(pkg):
+    rng = np.random.default_rng(3)
+    g = Group(pkg, 3)
+    img = cases.field(150, 203, 8)                       # w % 4 != 0: every rank votes for the general form
+    seeds = ol.find_local_minima(img)
+    got, _ = g.segment_tiled(img, seeds)
+    assert (got == ol.segment(img, seeds)).all()
+    img = cases.field(160, 256, 9)
+    seeds = np.asarray(ol.find_local_minima(img))
+    shuffled = seeds[rng.permutation(len(seeds))]        # rows not sorted: seeds dealt out one by one with explicit colours
+    got, _ = g.segment_tiled(img, shuffled)
+    assert (got == ol.segment(img, shuffled)).all()
+    dup = np.concatenate([seeds, seeds[::7]])            # rows sorted within each half only, and duplicates: later entries win
+    got, _ = g.segment_tiled(img, dup)
+    assert (got == ol.segment(img, dup)).all()
+    samerow = seeds.copy()
+    samerow[5], samerow[6] = seeds[6].copy(), seeds[5].copy()      # rows still sorted, list not strictly increasing: ws_block_begin refuses, vote
+    if samerow[5][0] == samerow[6][0]:
+        got, _ = g.segment_tiled(img, samerow)
+        assert (got == ol.segment(img, samerow)).all()
+    g.close()
+
+
+def test_tiled_edge_correction_and_seed_shift(pkg):
+    img = cases.field(120, 128, 12)
+    seeds = ol.find_local_minima(img)
+    g = Group(pkg, 3)
+    got, _ = g.segment_tiled(img, seeds, edge=True)
+    assert got.shape == (122, 130)
+    assert (got == ol.segment(img, seeds, edge=True)).all()           # lib.rs:1675-1677: seeds index the padded plane unshifted
+    ws = pkg.TransformBuilder.new().enable_edge_correction().shift_seeds_into_padded_plane().build_segmenting() \
+        if hasattr(pkg.TransformBuilder, "shift_seeds_into_padded_plane") else None
+    got2, _ = g.segment_tiled(img, seeds, edge=True, seed_shift=True)
+    moved = np.asarray(seeds, dtype=np.int64) + 1
+    pad = np.zeros((122, 130), np.uint8)
+    pad[1:-1, 1:-1] = img
+    assert (got2 == ol.segment(pad, moved)).all()
+    if ws is not None:
+        assert (got2 == ws.transform(img, seeds)).all()
+    g.close()
+
+
+def test_tiled_errors(pkg):
+    ffi = pkg._ffi
+    g = Group(pkg, 4)
+    img = cases.field(64, 64, 1)
+    seeds = ol.find_local_minima(img)
+    bad = np.concatenate([np.asarray(seeds), [[64, 3]]])
+    g.segment_tiled(img, bad, expect=ffi.WS_ERR_SEED_OOB)            # the reference panics: lib.rs:1676
+    g.segment_tiled(img[:3], np.zeros((0, 2)), expect=ffi.WS_ERR_BAD_ARG)      # fewer rows than ranks
+    out, _ = g.segment_tiled(img, seeds)                               # the group is usable after an error
+    assert (out == ol.segment(img, seeds)).all()
+    opt = ffi.Options(0)
+    rc = g.L.ws_segment_tiled(g.h, img.ctypes.data, 64, 64, 64, None, 0, ctypes.byref(opt), 0, out.ctypes.data, None)
+    assert rc == ffi.WS_ERR_MAX_TOO_LOW
+    g.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_tiled_device_8192_equals_single_domain(pkg, n_ranks):
+    # the headline field in row blocks, device resident, against the single-domain transform (oracle-checked at this
+    # size in test_gpu_oracle_at_size.py): every owned row, segmenting and merging
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    H = W = 8192
+    img = eng.random_field(H, W, 1)
+    seeds = eng.find_local_minima(img).clone()
+    want = eng.segment(img, seeds)
+    want_m = eng.merge(img, seeds, max_level=150)
+    torch.cuda.synchronize()
+    g = Group(pkg, n_ranks)
+    L, ffi = g.L, pkg._ffi
+    rows = seeds[:, 0].contiguous()
+    blocks = (ffi.TileBlock * n_ranks)()
+    keep = []
+    spans = []
+    for r in range(n_ranks):
+        v = [ctypes.c_size_t() for _ in range(4)]
+        assert L.ws_tile_rows(H, r, n_ranks, *[ctypes.byref(x) for x in v]) == 0
+        r0, r1, lo, hi = (x.value for x in v)
+        b = torch.searchsorted(rows, torch.tensor([lo, hi], dtype=rows.dtype, device=rows.device))
+        i0, i1 = int(b[0]), int(b[1])
+        loc = seeds[i0:i1].clone()
+        loc[:, 0] -= lo
+        bi = img[lo:hi].contiguous()
+        lab = torch.empty((hi - lo, W), dtype=torch.int32, device=eng.device)
+        keep += [loc, bi, lab]
+        spans.append((r0, r1, lo, lab))
+        blocks[r] = ffi.TileBlock(bi.data_ptr(), loc.data_ptr(), None, i1 - i0, i0 + 1, 0, lab.data_ptr())
+    torch.cuda.synchronize()
+    opt = ffi.Options(254)
+    rounds = ctypes.c_uint32(0)
+    rc = L.ws_segment_tiled_device(g.h, H, W, int(seeds.shape[0]), blocks, ctypes.byref(opt), 0, ctypes.byref(rounds))
+    assert rc == 0, (rc, g.err())
+    for r0, r1, lo, lab in spans:
+        assert bool((lab[r0 - lo:r1 - lo] == want[r0:r1]).all())
+    assert 3 <= rounds.value <= 12
+    opt = ffi.Options(150)
+    rc = L.ws_segment_tiled_device(g.h, H, W, int(seeds.shape[0]), blocks, ctypes.byref(opt), 1, None)
+    assert rc == 0, (rc, g.err())
+    for r0, r1, lo, lab in spans:
+        assert bool((lab[r0 - lo:r1 - lo] == want_m[r0:r1]).all())
+    g.close()
+
+
+def test_batch_group_equals_slice_by_slice(pkg):
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    S, H, W, n_ranks = 6, 512, 512, 3
+    g = Group(pkg, n_ranks)
+    ffi, L = pkg._ffi, g.L
+    parts = (ffi.BatchPart * n_ranks)()
+    keep, want, outs = [], {}, []
+    for r in range(n_ranks):
+        mine = list(range(r, S, n_ranks))                  # slice i -> rank i % world
+        cube = torch.empty((len(mine), H, W), dtype=torch.uint8, device=eng.device)
+        sl, offs = [], [0]
+        for j, k in enumerate(mine):
+            cube[j] = eng.random_field(H, W, 40 + k)
+            s = eng.find_local_minima(cube[j]).clone()
+            want[k] = eng.segment(cube[j], s).clone()
+            sl.append(s)
+            offs.append(offs[-1] + int(s.shape[0]))
+        allseeds = torch.cat(sl).contiguous()
+        lab = torch.empty((len(mine), H, W), dtype=torch.int32, device=eng.device)
+        co = (ctypes.c_size_t * len(offs))(*offs)
+        keep += [cube, allseeds, lab, co]
+        outs.append((mine, lab))
+        parts[r] = ffi.BatchPart(cube.data_ptr(), allseeds.data_ptr(), co, len(mine), lab.data_ptr())
+    torch.cuda.synchronize()
+    opt = ffi.Options(254)
+    fr, fs = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = L.ws_segment_batch_group(g.h, H, W, parts, ctypes.byref(opt), ctypes.byref(fr), ctypes.byref(fs))
+    assert rc == 0, (rc, g.err())
+    for mine, lab in outs:
+        for j, k in enumerate(mine):
+            assert bool((lab[j] == want[k]).all()), k
+    g.close()
