@@ -5,11 +5,14 @@
 
 headline (default)  one 8192x8192 u8 random field per GPU, device-resident: BASELINE's metric.  N GPUs = N independent
                     fields, no collective on the data path ("weak").
-c3                  BASELINE config 3: the MERGING transform (final canonical labels) of one 8192x8192 field per GPU.
+c3                  BASELINE config 3: the MERGING transform of one 8192x8192 field per GPU as the reference defines its
+                    output: transform_to_list, the lake sizes of all 255 levels (lib.rs:1551-1561, tests/core_bench.rs:48),
+                    records left in HBM.  c3-final: the final canonical labels only (`transform` is a stub in the reference).
 c4                  BASELINE config 4: a batch of 64 independent 4096x4096 slices, slice i on rank i % N, each rank's
                     slices as ONE stacked transform (ws_segment_batch_device).  Total work fixed ("strong").
-c5                  BASELINE config 5: one 32768x32768 field in row blocks over the ranks, halo rows exchanged through
-                    torch.distributed (RCCL on GPUs): rustronomy-watershed_amd/distributed.py.  "strong".
+c5                  BASELINE config 5: one 32768x32768 field in row blocks over the ranks: ws_segment_tiled_device, the loop
+                    inside the library (csrc/ws_tiled.hip), halo rows / flag / tables through RCCL when every rank has a
+                    GPU of its own; `--local-ranks R` on one process: R virtual ranks on one device.  "strong".
 
 A "step" is one pass of the whole hot path over the configuration's input (seed tables, all 255 water levels, final
 labels); image and seeds are resident in HBM before the timed region, u32 labels stay in HBM.
@@ -46,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20)      # transforms are 0.6 ms: twenty bring the clocks up and let the graph capture (2nd call) settle
-    ap.add_argument("--config", choices=["headline", "c3", "c4", "c5"], default="headline")
+    ap.add_argument("--config", choices=["headline", "c3", "c3-final", "c4", "c5"], default="headline")
     ap.add_argument("--size", type=int, default=0, help="override the field side (headline: 8192, c4 slices: 4096, c5: 32768)")
     ap.add_argument("--slices", type=int, default=C4_SLICES, help="c4: slices in the batch")
     ap.add_argument("--engine", choices=["fused", "sweep"], default="fused")
@@ -54,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the one CPU run of the bench field itself (~45 s at 8192^2)")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / cpu_baseline")
+    ap.add_argument("--local-ranks", type=int, default=1, help="c5 on ONE process: virtual ranks of the local group (1: the field whole)")
     ap.add_argument("--contexts", type=int, default=4, help="headline: engine contexts that take turns, each on its own stream (1: as --no-pipeline)")
     ap.add_argument("--one-stream", action="store_true", help="headline: all contexts on one stream (transforms queue up, never overlap)")
     ap.add_argument("--no-pipeline", action="store_true", help="headline: one context, every transform waited for before the next is queued (the default takes turns on two contexts: ws_segment_device_begin / _end)")
@@ -210,6 +214,7 @@ def run(args):
     import importlib
     dev = importlib.import_module("rustronomy_watershed_amd.device")
     wsd = importlib.import_module("rustronomy_watershed_amd.distributed")
+    wsg = importlib.import_module("rustronomy_watershed_amd.group")
     torch.cuda.set_device(dev_index)
     # a real stream for everything (torch's default is the legacy null stream, on which nothing can be captured): the
     # engine replays the first passes of a transform that repeats the previous one's buffers as one hipGraph launch
@@ -224,6 +229,9 @@ def run(args):
     # ---- the configuration's input, resident in HBM, and its step ------------------------------------------------------
     cfg = args.config
     pipelined = False
+    to_list = cfg == "c3"            # BASELINE config 3 as the reference defines the merging transform's output (below)
+    if cfg == "c3-final":
+        cfg = "c3"
     if cfg in ("headline", "c3"):
         H = W = args.size or 8192
         img = eng.random_field(H, W, 1 + 16 * rank)     # independent fields per rank (and per context: below)
@@ -233,7 +241,26 @@ def run(args):
         px_per_step_all_ranks = world * H * W
         scaling = "weak"
         merging = cfg == "c3"       # segmenting flood + one union pass over the image + relabel
-        if args.no_pipeline or args.contexts < 2 or args.engine == "sweep":
+        c3_info = None
+        if to_list:
+            # The merging transform's only real output in the reference is transform_to_list (lib.rs:1551-1561; what
+            # tests/core_bench.rs:48 times): (level, lake sizes) for all 255 levels -- `transform` itself is a stub
+            # (lib.rs:1524-1536).  One step = ws_transform_to_list_device: the flood, the per-level unions and the sparse
+            # (colour, area) records of every level, left in HBM; only the 256 offsets and 255 uncoloured counts reach the host.
+            lakes_buf, offsets, _unc = eng.transform_to_list(img, seeds, merging=True)
+            n_records = int(offsets[-1])
+            lakes_buf = torch.empty((n_records + 1024, 2), dtype=torch.int64, device=eng.device)
+            seg = eng.segment(img, seeds)
+            a, b = seg[:, :-1], seg[:, 1:]
+            n_edges = int(((a != b) & (a != 0) & (b != 0)).sum().item())
+            a, b = seg[:-1, :], seg[1:, :]
+            n_edges += int(((a != b) & (a != 0) & (b != 0)).sum().item())
+            del seg, a, b
+            c3_info = {"records": n_records, "crossing_edges": n_edges, "levels": 255}
+
+            def step():
+                eng.transform_to_list(img, seeds, merging=True, lakes=lakes_buf)
+        elif args.no_pipeline or args.contexts < 2 or args.engine == "sweep":
             def step():
                 (eng.merge if merging else eng.segment)(img, seeds, out=labels)
         else:
@@ -278,7 +305,7 @@ def run(args):
                         pipe["pending"][i] = False
                 pipe["k"] = 0
             pipelined = True
-        workload = (f"{H}x{W} u8 uniform[0,254) random field per GPU, {'MERGING transform (final canonical labels)' if cfg == 'c3' else 'segmenting transform'}, max_water_level 254, "
+        workload = (f"{H}x{W} u8 uniform[0,254) random field per GPU, {('MERGING transform, transform_to_list: lake records of all 255 levels (ws_transform_to_list_device)' if to_list else 'MERGING transform (final canonical labels)') if cfg == 'c3' else 'segmenting transform'}, max_water_level 254, "
                     f"seeds = find_local_minima ({n_seeds} on rank 0's first field), engine {args.engine}"
                     + (f"; {args.contexts} contexts in flight, each transforming ITS OWN field and seed list (generator seeds 1..{args.contexts})" if pipelined else ""))
         parallelism = f"independent fields x{world}"
@@ -299,36 +326,69 @@ def run(args):
         px_per_step_all_ranks = args.slices * H * W
         scaling = "strong"
 
+        # the batch goes through ws_segment_batch_group (csrc/ws_tiled.hip): this process drives ONE rank of the job (a local
+        # group of one rank on its own device) -- independent slices need no exchange step, so no RCCL communicator is made
+        grp = wsg.Group.local(1, [dev_index])
+
         def step():
             if mine:
-                eng.segment_batch(cube, seeds, offs, out=labels)
+                grp.segment_batch(H, W, [(cube, seeds, offs, labels)])
         workload = (f"batch of {args.slices} independent {H}x{W} u8 random slices (CGPS-like cube), segmenting, slice i on rank "
-                    f"i % {world}; a rank's {len(mine)} slices run as one stacked transform (ws_segment_batch_device)")
+                    f"i % {world}; a rank's {len(mine)} slices run as one stacked transform (ws_segment_batch_group -> ws_segment_batch_device)")
         parallelism = f"independent slices, {len(mine)} per GPU x{world}, no data-path collective"
         units = {"slices_total": args.slices, "slices_per_gpu": len(mine)}
     else:   # c5
         H = W = args.size or C5_SIDE
-        r0, r1, lo, hi = wsd.row_block(H, rank, world)
-        full = eng.random_field(H, W, 5)                # every rank generates the field and keeps its rows (+ halo rows)
-        all_seeds = eng.find_local_minima(full)         # global list; a rank's seeds are a contiguous range of it
-        block_img = full[lo:hi].contiguous()
-        n_all = int(all_seeds.shape[0])
-        sl, colours = wsd.local_seeds(all_seeds, lo, hi)
-        del full, all_seeds
-        torch.cuda.empty_cache()
-        block = wsd.HipBlockEngine(eng, block_img, sl, colours)
+        rounds_seen = []
+        vranks = max(args.local_ranks, 1)
+        use_c_group = world == 1 or backend == "nccl"
+        if use_c_group:
+            # ws_segment_tiled_device (csrc/ws_tiled.hip): the tiled loop runs inside the library.  One rank per process and
+            # GPU -> an RCCL group (halo rows by ncclSend / ncclRecv, the flag by ncclAllReduce, tables by ncclAllGather over
+            # xGMI); a single process -> a LOCAL group of --local-ranks virtual ranks on its one device (1: the whole field).
+            if world > 1:
+                grp = wsg.Group.rccl_over_torch(dev_index, rank, world, comm_dev)
+                grp.selftest()
+            else:
+                grp = wsg.Group.local(vranks, [dev_index] * vranks)
+            full = eng.random_field(H, W, 5)                # every rank generates the field and keeps its rows (+ halo rows)
+            all_seeds = eng.find_local_minima(full).clone() # global list; a rank's seeds are a contiguous range of it
+            n_all = int(all_seeds.shape[0])
+            blocks, spans, keep = grp.make_blocks(H, lambda lo, hi, r: full[lo:hi].contiguous() if grp.world > 1 else full, all_seeds)
+            r0, r1 = spans[0][0], spans[0][1]
+            if grp.world > 1:
+                del full
+            del all_seeds
+            torch.cuda.empty_cache()
+
+            def step():
+                rounds_seen.append(grp.segment_tiled_device(H, W, n_all, blocks))
+            labels = None
+            how = (f"ws_segment_tiled_device, RCCL group of {world} ranks (grouped ncclSend/ncclRecv halo rows, 1-word ncclAllReduce, ncclAllGather of the boundary table)"
+                   if world > 1 else f"ws_segment_tiled_device, local group of {vranks} rank(s) on one device")
+        else:
+            # rehearsal with more ranks than GPUs: RCCL refuses two ranks on one device, so the caller-driven form
+            # (distributed.py: the same block steps, collectives over gloo) stands in
+            r0, r1, lo, hi = wsd.row_block(H, rank, world)
+            full = eng.random_field(H, W, 5)
+            all_seeds = eng.find_local_minima(full)
+            block_img = full[lo:hi].contiguous()
+            n_all = int(all_seeds.shape[0])
+            sl, colours = wsd.local_seeds(all_seeds, lo, hi)
+            del full, all_seeds
+            torch.cuda.empty_cache()
+            block = wsd.HipBlockEngine(eng, block_img, sl, colours)
+
+            def step():
+                _, rounds = wsd.segment_tiled(block, rank, world)
+                rounds_seen.append(rounds)
+            labels = None
+            how = f"distributed.py over {backend} (ranks share devices: a protocol rehearsal)"
         n_seeds = n_all
         px_per_step_all_ranks = H * W
         scaling = "strong"
-        rounds_seen = []
-
-        def step():
-            _, rounds = wsd.segment_tiled(block, rank, world)
-            rounds_seen.append(rounds)
-        labels = None
-        workload = (f"one {H}x{W} u8 random field, segmenting, row blocks of {r1 - r0} rows per GPU with 1-row halos, "
-                    f"halo exchange + 1-word all-reduce per round over {backend or 'no collective (1 rank)'}")
-        parallelism = f"row-blocked tiles x{world}"
+        workload = (f"one {H}x{W} u8 random field, segmenting, row blocks of {r1 - r0} rows per rank with 1-row halos; {how}")
+        parallelism = f"row-blocked tiles x{world if world > 1 else vranks}"
         units = {"rows_per_gpu": r1 - r0}
 
     for _ in range(args.warmup):
@@ -476,10 +536,34 @@ def run(args):
         roof["sweep_model_speed_equivalent"] = {"bytes_per_step": int(b_sweep), "equivalent_GBps": round(sweep_equiv, 1),
                                                  "times_hbm_peak": round(sweep_equiv / HBM_PEAK_GBS, 3),
                                                  "note": "speed-equivalent of a sweep-per-level engine, not bandwidth"}
+        # The other ceiling: vector issue.  The transform's kernels execute `lane_instr_per_px` vector instructions
+        # per pixel (SQ_INSTS_VALU, profiles/valu.json: a single-context profile of this build's kernels) and a SIMD spends
+        # `cycles_per_wave_instr` cycles on each (SQ_ACTIVE_INST_VALU; the microbenchmark has the same figure for the relaxation's
+        # mix: v_min3 / v_med3 / v_min issue at half rate on gfx950).  peak = 1024 SIMDs x 64 lanes x 2.4 GHz / that.
+        roof_valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu.json")
+        if cfg == "headline" and args.engine == "fused" and H == 8192 and os.path.exists(vpath):
+            vj = json.load(open(vpath))
+            cpi = float(vj["cycles_per_wave_instr_measured"])
+            peak_mix = 1024 * 64 * 2.4e9 / cpi
+            lane_ops = float(vj["lane_instr_per_px"]) * npx_rank
+            roof_valu = {"peak_lane_ops_per_s": round(peak_mix, 0), "peak_note": f"1024 SIMDs x 64 lanes x 2.4 GHz / {cpi:.2f} cycles per wave-instruction of THIS instruction mix "
+                                                                              "(full-rate instructions alone: 3.2 cycles measured, 2 by the data sheet)",
+                         "lane_ops_per_px": round(float(vj["lane_instr_per_px"]), 1), "lane_ops_per_step": int(lane_ops),
+                         "achieved_lane_ops_per_s": round(lane_ops / (ms_step * 1e-3), 0), "frac": round(lane_ops / (ms_step * 1e-3) / peak_mix, 4),
+                         "frac_of_datasheet_peak": round(lane_ops / (ms_step * 1e-3) / (1024 * 64 * 2.4e9 / 2.0), 4),
+                         "floor_ms_per_step": round(lane_ops / peak_mix * 1e3, 4), "source": vj["source"], "microbenchmark": vj["microbenchmark"]}
+            if ms_one_context is not None:
+                roof_valu["frac_one_transform_alone"] = round(lane_ops / (ms_one_context * 1e-3) / peak_mix, 4)
+            roof["tighter_bound"] = "valu" if roof_valu["frac"] > roof.get("frac_compulsory", 0.0) else "hbm"
+            roof["tighter_bound_note"] = ("pass 0 of the relaxation and k_resolve_local keep a vector instruction active on every SIMD 88 % / 83 % of their cycles "
+                                          "(profiles/r3_v0_issue_counters.json): the transform is bound by vector issue, not by HBM; `bound` stays \"hbm\" because "
+                                          "BASELINE's metric is phrased against the HBM roofline")
         out = {
             "metric": ("Mpixels/s segmenting watershed, 8192x8192 u8, device-resident"
                        + (f" (throughput, {args.contexts} transforms of distinct fields in flight; one transform alone: value_one_transform_alone)" if pipelined else "")) if cfg == "headline"
-                      else ("Mpixels/s merging watershed (final labels), 8192x8192 u8, BASELINE config c3, device-resident" if cfg == "c3"
+                      else (("Mpixels/s merging watershed, transform_to_list (lake sizes of all 255 levels, lib.rs:1551-1561), 8192x8192 u8, BASELINE config c3, device-resident"
+                             if to_list else "Mpixels/s merging watershed (final canonical labels only), 8192x8192 u8, BASELINE config c3, device-resident") if cfg == "c3"
                             else f"Mpixels/s segmenting watershed, BASELINE config {cfg}, device-resident"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -498,7 +582,20 @@ def run(args):
                                        if ms_one_context is not None else "")},
                            **units),
             "roofline": roof,
+            "roofline_valu": roof_valu,
         }
+        if c3_info is not None:
+            # compulsory bytes of the list part: every crossing edge read once (8 B), every lake record
+            # written once (16 B), on top of the flood's own
+            b_list = 8 * c3_info["crossing_edges"] + 16 * c3_info["records"]
+            c3_info.update({"records_per_s": round(c3_info["records"] / (ms_step * 1e-3), 0),
+                            "list_bytes_compulsory": int(b_list), "frac_compulsory_with_list": round((b_min + b_list) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.merge(img, seeds, out=labels)
+            torch.cuda.synchronize()
+            c3_info["final_labels_only_ms"] = round((time.perf_counter() - t1) * 1e3 / args.steps, 4)
+            out["c3"] = c3_info
         if ms_one_context is not None:      # the time of ONE transform when nothing else is in flight (the one-call form)
             out["config"]["contexts_in_flight"] = args.contexts
             out["config"]["ms_one_transform_alone"] = round(ms_one_context, 4)

@@ -1,0 +1,133 @@
+"""ws_group_* of include/ws_hip.h on torch tensors: several ranks behind one C call (csrc/ws_tiled.hip).
+
+A `Group` is LOCAL (all ranks driven by this process, rank r on `devices[r]`; ranks may share a device) or RCCL (this
+process is one rank of `world`, one GPU per process: the 128-byte id comes from rank 0 and travels through whatever the
+job already has -- here torch.distributed.broadcast).  The loop that distributed.py spells out over torch.distributed
+runs inside the library; torch only allocates the tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+
+
+class Group:
+    def __init__(self, handle, world, n_local, first_local):
+        self._h = handle
+        self.world, self.n_local, self.first_local = world, n_local, first_local
+
+    # ---- construction ----------------------------------------------------------------------------------------------------
+    @classmethod
+    def local(cls, n_ranks, devices=None):
+        h = ctypes.c_void_p()
+        dev = (ctypes.c_int * n_ranks)(*devices) if devices is not None else None
+        rc = _ffi.lib().ws_group_create_local(n_ranks, dev, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ws_group_create_local: {_ffi.lib().ws_strerror(rc).decode()}")
+        return cls._wrap(h)
+
+    @classmethod
+    def rccl(cls, device, rank, world, broadcast_bytes):
+        """`broadcast_bytes(buf_or_None) -> bytes`: hands rank 0's 128 id bytes to every rank (rank 0 passes them in)."""
+        L = _ffi.lib()
+        uid = ctypes.create_string_buffer(_ffi.WS_RCCL_ID_BYTES)
+        if rank == 0:
+            rc = L.ws_group_rccl_unique_id(uid)
+            if rc != 0:
+                raise RuntimeError(f"ws_group_rccl_unique_id: {L.ws_strerror(rc).decode()}: {L.ws_group_last_error(None).decode()}")
+        raw = broadcast_bytes(bytes(uid.raw) if rank == 0 else None)
+        uid = ctypes.create_string_buffer(raw, _ffi.WS_RCCL_ID_BYTES)
+        h = ctypes.c_void_p()
+        rc = L.ws_group_create_rccl(device, rank, world, uid, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ws_group_create_rccl: {L.ws_strerror(rc).decode()}: {L.ws_group_last_error(None).decode()}")
+        return cls._wrap(h)
+
+    @classmethod
+    def rccl_over_torch(cls, device, rank, world, comm_device):
+        """The id travels as a 128-byte tensor through torch.distributed (any backend)."""
+        import torch.distributed as dist
+
+        def bcast(raw):
+            t = torch.zeros(_ffi.WS_RCCL_ID_BYTES, dtype=torch.uint8, device=comm_device)
+            if raw is not None:
+                t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        return cls.rccl(device, rank, world, bcast)
+
+    @classmethod
+    def _wrap(cls, h):
+        w, n, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _ffi.lib().ws_group_info(h, ctypes.byref(w), ctypes.byref(n), ctypes.byref(f))
+        return cls(h, w.value, n.value, f.value)
+
+    def close(self):
+        if self._h:
+            _ffi.lib().ws_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {_ffi.lib().ws_strerror(rc).decode()}: {_ffi.lib().ws_group_last_error(self._h).decode()}")
+
+    def selftest(self):
+        self._check(_ffi.lib().ws_group_selftest(self._h), "ws_group_selftest")
+
+    # ---- one field in row blocks ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def tile_rows(h, rank, world):
+        v = [ctypes.c_size_t() for _ in range(4)]
+        rc = _ffi.lib().ws_tile_rows(h, rank, world, *[ctypes.byref(x) for x in v])
+        if rc != 0:
+            raise ValueError(f"a field of {h} rows cannot be split into {world} row blocks")
+        return tuple(x.value for x in v)
+
+    def make_blocks(self, field_rows, img_rows_of, seeds, devices=None):
+        """Descriptors of the LOCAL ranks' blocks.  `img_rows_of(lo, hi, rank)`: the rank's rows [lo, hi) of the field as a
+        contiguous uint8 tensor on the rank's device; `seeds`: the field's strictly increasing (row, col) list, int32 (n, 2),
+        on any device.  Returns (ctypes array, [(r0, r1, lo, labels)], keep-alive list)."""
+        rows = seeds[:, 0].contiguous()
+        blocks = (_ffi.TileBlock * self.n_local)()
+        spans, keep = [], []
+        for i in range(self.n_local):
+            rank = self.first_local + i
+            r0, r1, lo, hi = self.tile_rows(field_rows, rank, self.world)
+            b = torch.searchsorted(rows, torch.tensor([lo, hi], dtype=rows.dtype, device=rows.device))
+            i0, i1 = int(b[0]), int(b[1])
+            img = img_rows_of(lo, hi, rank)
+            loc = seeds[i0:i1].to(img.device).clone()
+            loc[:, 0] -= lo
+            lab = torch.empty((hi - lo, img.shape[1]), dtype=torch.int32, device=img.device)
+            keep += [img, loc, lab]
+            spans.append((r0, r1, lo, lab))
+            blocks[i] = _ffi.TileBlock(img.data_ptr(), loc.data_ptr() if i1 > i0 else None, None, i1 - i0, i0 + 1, 0, lab.data_ptr())
+        return blocks, spans, keep
+
+    def segment_tiled_device(self, field_rows, width, n_seeds_total, blocks, max_level=254, merging=False):
+        opt = _ffi.Options(max_level)
+        rounds = ctypes.c_uint32(0)
+        self._check(_ffi.lib().ws_segment_tiled_device(self._h, field_rows, width, n_seeds_total, blocks, ctypes.byref(opt), int(merging),
+                                                       ctypes.byref(rounds)), "ws_segment_tiled_device")
+        return rounds.value
+
+    # ---- a batch of independent slices ------------------------------------------------------------------------------------------
+    def segment_batch(self, h, w, parts, max_level=254):
+        """parts: one (cube (S, h, w) uint8, seeds (n, 2) int32, offsets list of S + 1, labels (S, h, w) int32) per LOCAL rank."""
+        arr = (_ffi.BatchPart * self.n_local)()
+        keep = []
+        for i, (cube, seeds, offs, labels) in enumerate(parts):
+            co = (ctypes.c_size_t * len(offs))(*[int(x) for x in offs])
+            keep.append(co)
+            arr[i] = _ffi.BatchPart(cube.data_ptr() if cube.numel() else None, seeds.data_ptr() if seeds.numel() else None, co, cube.shape[0],
+                                    labels.data_ptr() if labels.numel() else None)
+        fr, fs = ctypes.c_size_t(), ctypes.c_size_t()
+        opt = _ffi.Options(max_level)
+        self._check(_ffi.lib().ws_segment_batch_group(self._h, h, w, arr, ctypes.byref(opt), ctypes.byref(fr), ctypes.byref(fs)), "ws_segment_batch_group")

@@ -219,9 +219,46 @@ static int shim_sequence_checks() {
   return 0;
 }
 
+// Several ranks behind the same call (include/ws_hip.h, ws_group_*): what a TiledWatershed wrapper of the shim would do for
+// transform() -- one local group, ws_segment_tiled with host buffers -- against the oracle's single-domain transform
+// (lib.rs:1638-1808 and 1328-1522 in one address space).  Three ranks on device 0: the protocol, not the speed.
+static int group_sequence_checks() {
+  const size_t H = 300, W = 256;
+  std::vector<uint8_t> img(H * W);
+  ws_or_random_field(img.data(), H, W, 23);
+  std::vector<uint64_t> rc_pairs(H * W);
+  const size_t n = ws_or_find_local_minima(img.data(), H, W, rc_pairs.data(), H * W / 2);
+  CHECK(n > 100);
+  ws_group *g = nullptr;
+  const int devices[3] = {0, 0, 0};
+  CHECK(ws_group_create_local(3, devices, &g) == WS_OK);
+  int world = 0, n_local = 0, first = -1;
+  CHECK(ws_group_info(g, &world, &n_local, &first) == WS_OK && world == 3 && n_local == 3 && first == 0);
+  CHECK(ws_group_selftest(g) == WS_OK);
+  size_t r0, r1, lo, hi;
+  CHECK(ws_tile_rows(H, 1, 3, &r0, &r1, &lo, &hi) == WS_OK && r0 == 100 && r1 == 200 && lo == 99 && hi == 201);
+  ws_options o;
+  ws_options_default(&o);
+  std::vector<uint64_t> out(H * W), want(H * W);
+  uint32_t rounds = 0;
+  CHECK(ws_segment_tiled(g, img.data(), H, W, W, rc_pairs.data(), n, &o, 0, out.data(), &rounds) == WS_OK);
+  CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 0, want.data(), nullptr) == 0);
+  CHECK(out == want && rounds >= 3);
+  o.max_water_level = 90;
+  CHECK(ws_segment_tiled(g, img.data(), H, W, W, rc_pairs.data(), n, &o, 1, out.data(), nullptr) == WS_OK);
+  CHECK(ws_or_merge_arrival(img.data(), H, W, rc_pairs.data(), n, 90, 0, want.data(), nullptr, nullptr) == 0);
+  CHECK(out == want);
+  const uint64_t bad[2] = {H, 0};
+  CHECK(ws_segment_tiled(g, img.data(), H, W, W, bad, 1, &o, 0, out.data(), nullptr) == WS_ERR_SEED_OOB);
+  CHECK(std::strlen(ws_group_last_error(g)) > 0);
+  ws_group_destroy(g);
+  std::printf("group sequence ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   if (cpu_checks()) return 1;
-  if (gpu) return gpu_checks() || shim_sequence_checks();
+  if (gpu) return gpu_checks() || shim_sequence_checks() || group_sequence_checks();
   return no_device_check();
 }

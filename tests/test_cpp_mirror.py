@@ -40,3 +40,4 @@ def test_cpp_mirror_gpu():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu checks ok" in out.stdout
     assert "shim sequence ok" in out.stdout          # the Rust shim's ABI call order, executed from C++
+    assert "group sequence ok" in out.stdout         # three ranks behind ws_segment_tiled (local group), vs the oracle

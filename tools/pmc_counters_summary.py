@@ -11,14 +11,14 @@ import sys
 def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(lambda: collections.defaultdict(set))
-    for path in sys.argv[1:]:
+    for fi, path in enumerate(sys.argv[1:]):
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"].split("(")[0]
             if name.startswith("void "):
                 name = name[5:]
             c = row["Counter_Name"]
             acc[name][c] += float(row["Counter_Value"])
-            cnt[name][c].add(row["Dispatch_Id"])
+            cnt[name][c].add((fi, row["Dispatch_Id"]))      # a counter may sit in several passes: every (pass, dispatch) is one sample
     out = {}
     for k in sorted(acc):
         out[k] = {"launches": max(len(v) for v in cnt[k].values())}
