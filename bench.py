@@ -229,6 +229,7 @@ def run(args):
     # ---- the configuration's input, resident in HBM, and its step ------------------------------------------------------
     cfg = args.config
     pipelined = False
+    c3_info = None
     to_list = cfg == "c3"            # BASELINE config 3 as the reference defines the merging transform's output (below)
     if cfg == "c3-final":
         cfg = "c3"
@@ -241,7 +242,6 @@ def run(args):
         px_per_step_all_ranks = world * H * W
         scaling = "weak"
         merging = cfg == "c3"       # segmenting flood + one union pass over the image + relabel
-        c3_info = None
         if to_list:
             # The merging transform's only real output in the reference is transform_to_list (lib.rs:1551-1561; what
             # tests/core_bench.rs:48 times): (level, lake sizes) for all 255 levels -- `transform` itself is a stub

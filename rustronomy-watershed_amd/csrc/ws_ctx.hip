@@ -234,7 +234,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->seeds64,
-                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->uf_death, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
+                    &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->uf_death, &c->uf_sd, &c->alive, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);

@@ -47,7 +47,7 @@ struct ws_ctx {
   ws_stats stats{};
 
   wsapi::DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
-  wsapi::DevBuf uf_parent, uf_size, uf_hooked, uf_death, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
+  wsapi::DevBuf uf_parent, uf_size, uf_hooked, uf_death, uf_sd, alive, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   uint32_t *pinned_dev = nullptr;  // the same words as the device sees them (nullptr: not mapped, copies only)
   hipEvent_t ring_ev[wsk::COUNTER_RING]{};   // flag slot copied to the host

@@ -120,20 +120,30 @@ __device__ __forceinline__ void gather_items(const uint32_t *__restrict__ keys, 
   }
 }
 
+// A workgroup takes SEG_RUN consecutive row segments (one per step), not one: the 512 level counters are hit once per
+// workgroup and level, and with a workgroup per 1024 pixels those same-address atomics (~12 ns each) WERE the kernel --
+// 8192^2: 33 M of them on 512 words, 1.4 ms for 0.5 GB of reads.
+constexpr int SEG_RUN = 16;
+
 __global__ __launch_bounds__(256) void k_level_hist(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
                                                     int H, int W, int segs, u64c *hist_px, u64c *hist_edge) {
   __shared__ uint32_t s_px[NLEVELS], s_ed[NLEVELS];
   s_px[threadIdx.x] = 0;
   s_ed[threadIdx.x] = 0;
   __syncthreads();
-  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
-  PixelItems it;
-  gather_items(keys, labels, H, W, y, seg * MSEG + threadIdx.x * 4, it);
+  const size_t total = (size_t)H * segs;
+  for (int j = 0; j < SEG_RUN; ++j) {
+    const size_t sg = (size_t)blockIdx.x * SEG_RUN + j;
+    if (sg >= total) break;
+    const int y = (int)(sg / segs), seg = (int)(sg % segs);
+    PixelItems it;
+    gather_items(keys, labels, H, W, y, seg * MSEG + threadIdx.x * 4, it);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (it.px_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_px[it.px_lvl[k]], 1u);
-    if (it.er_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.er_lvl[k]], 1u);
-    if (it.ed_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.ed_lvl[k]], 1u);
+    for (int k = 0; k < 4; ++k) {
+      if (it.px_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_px[it.px_lvl[k]], 1u);
+      if (it.er_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.er_lvl[k]], 1u);
+      if (it.ed_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.ed_lvl[k]], 1u);
+    }
   }
   __syncthreads();
   if (s_px[threadIdx.x]) atomicAdd(&hist_px[threadIdx.x], (u64c)s_px[threadIdx.x]);
@@ -144,7 +154,8 @@ hipError_t level_hist(hipStream_t s, const uint32_t *keys, const uint32_t *label
                       u64c *hist_px, u64c *hist_edge) {
   if (h == 0 || w == 0) return hipSuccess;
   const int segs = (w + MSEG - 1) / MSEG;
-  k_level_hist<<<h * segs, 256, 0, s>>>(keys, labels, h, w, segs, hist_px, hist_edge);
+  const size_t total = (size_t)h * segs;
+  k_level_hist<<<(unsigned)((total + SEG_RUN - 1) / SEG_RUN), 256, 0, s>>>(keys, labels, h, w, segs, hist_px, hist_edge);
   return hipGetLastError();
 }
 
@@ -175,6 +186,8 @@ hipError_t level_offsets(hipStream_t s, const u64c *hist_px, const u64c *hist_ed
   return hipGetLastError();
 }
 
+// Two walks over the workgroup's SEG_RUN segments: the first counts its items per level in LDS, then ONE reservation per
+// (workgroup, level), then the second walk gathers the items again (L2 still holds them) and writes them behind LDS cursors.
 __global__ __launch_bounds__(256) void k_level_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
                                                        int H, int W, int segs, u64c *cursor_px, u64c *cursor_edge,
                                                        uint32_t *px_items, uint2 *edge_items) {
@@ -183,14 +196,18 @@ __global__ __launch_bounds__(256) void k_level_scatter(const uint32_t *__restric
   s_px[threadIdx.x] = 0;
   s_ed[threadIdx.x] = 0;
   __syncthreads();
-  const int y = blockIdx.x / segs, seg = blockIdx.x % segs;
-  PixelItems it;
-  gather_items(keys, labels, H, W, y, seg * MSEG + threadIdx.x * 4, it);
+  const size_t total = (size_t)H * segs;
+  for (int j = 0; j < SEG_RUN; ++j) {
+    const size_t sg = (size_t)blockIdx.x * SEG_RUN + j;
+    if (sg >= total) break;
+    PixelItems it;
+    gather_items(keys, labels, H, W, (int)(sg / segs), (int)(sg % segs) * MSEG + threadIdx.x * 4, it);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (it.px_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_px[it.px_lvl[k]], 1u);
-    if (it.er_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.er_lvl[k]], 1u);
-    if (it.ed_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.ed_lvl[k]], 1u);
+    for (int k = 0; k < 4; ++k) {
+      if (it.px_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_px[it.px_lvl[k]], 1u);
+      if (it.er_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.er_lvl[k]], 1u);
+      if (it.ed_lvl[k] != 0xFFFFFFFFu) atomicAdd(&s_ed[it.ed_lvl[k]], 1u);
+    }
   }
   __syncthreads();
   // one global reservation per (workgroup, level) that has items
@@ -203,19 +220,25 @@ __global__ __launch_bounds__(256) void k_level_scatter(const uint32_t *__restric
   s_px[threadIdx.x] = 0;
   s_ed[threadIdx.x] = 0;
   __syncthreads();
+  for (int j = 0; j < SEG_RUN; ++j) {
+    const size_t sg = (size_t)blockIdx.x * SEG_RUN + j;
+    if (sg >= total) break;
+    PixelItems it;
+    gather_items(keys, labels, H, W, (int)(sg / segs), (int)(sg % segs) * MSEG + threadIdx.x * 4, it);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (it.px_lvl[k] != 0xFFFFFFFFu) {
-      const uint32_t l = it.px_lvl[k];
-      px_items[s_bpx[l] + atomicAdd(&s_px[l], 1u)] = it.px_col[k];
-    }
-    if (it.er_lvl[k] != 0xFFFFFFFFu) {
-      const uint32_t l = it.er_lvl[k];
-      edge_items[s_bed[l] + atomicAdd(&s_ed[l], 1u)] = it.er[k];
-    }
-    if (it.ed_lvl[k] != 0xFFFFFFFFu) {
-      const uint32_t l = it.ed_lvl[k];
-      edge_items[s_bed[l] + atomicAdd(&s_ed[l], 1u)] = it.ed[k];
+    for (int k = 0; k < 4; ++k) {
+      if (it.px_lvl[k] != 0xFFFFFFFFu) {
+        const uint32_t l = it.px_lvl[k];
+        px_items[s_bpx[l] + atomicAdd(&s_px[l], 1u)] = it.px_col[k];
+      }
+      if (it.er_lvl[k] != 0xFFFFFFFFu) {
+        const uint32_t l = it.er_lvl[k];
+        edge_items[s_bed[l] + atomicAdd(&s_ed[l], 1u)] = it.er[k];
+      }
+      if (it.ed_lvl[k] != 0xFFFFFFFFu) {
+        const uint32_t l = it.ed_lvl[k];
+        edge_items[s_bed[l] + atomicAdd(&s_ed[l], 1u)] = it.ed[k];
+      }
     }
   }
 }
@@ -224,7 +247,8 @@ hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *la
                          u64c *cursor_px, u64c *cursor_edge, uint32_t *px_items, uint2 *edge_items) {
   if (h == 0 || w == 0) return hipSuccess;
   const int segs = (w + MSEG - 1) / MSEG;
-  k_level_scatter<<<h * segs, 256, 0, s>>>(keys, labels, h, w, segs, cursor_px, cursor_edge, px_items, edge_items);
+  const size_t total = (size_t)h * segs;
+  k_level_scatter<<<(unsigned)((total + SEG_RUN - 1) / SEG_RUN), 256, 0, s>>>(keys, labels, h, w, segs, cursor_px, cursor_edge, px_items, edge_items);
   return hipGetLastError();
 }
 
@@ -421,6 +445,226 @@ hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range,
 hipError_t emit_lakes(hipStream_t s, const uint32_t *parent, const uint32_t *size, size_t n_colours,
                       uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t level, const uint32_t *death) {
   k_emit_lakes<<<(unsigned)emit_blocks_for(n_colours), 256, 0, s>>>(parent, size, n_colours, lakes, cap, level_counts, level, death);
+  return hipGetLastError();
+}
+
+// ---- merging transform_to_list at size: records from the list of LIVE lakes ------------------------------------------------
+//
+// k_emit_lakes looks at every colour at every level: 255 x S visits (8192^2: 1.9 G) for 0.62 G records -- 45 of the 67 ms of a
+// transform_to_list there.  A lake of level l was a lake of level l - 1 (every seed's colour holds its seed pixel from the
+// start, lib.rs:1670-1677, and lakes only ever merge), so level l's lakes are found among level l - 1's: the kernel below reads
+// the list of the lakes alive at the level before (all colours, for level 0), keeps those that are still roots with pixels, and
+// writes their records AND the next list in the same positions (one ticket per 4096 candidates).  Work per level: the live lakes.
+// sd[c] = (area, death level): one 8-byte gather per candidate.
+constexpr int ALIVE_PER_THREAD = 16;
+constexpr int ALIVE_CHUNK = 256 * ALIVE_PER_THREAD;
+
+__global__ void k_sd_init(uint2 *sd, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) sd[i] = make_uint2(0u, 0xFFFFFFFFu);
+}
+
+hipError_t sd_init(hipStream_t s, uint2 *sd, size_t n) {
+  if (n == 0) return hipSuccess;
+  k_sd_init<<<(unsigned)std::min<size_t>((n + 1023) / 1024, 8192), 256, 0, s>>>(sd, n);
+  return hipGetLastError();
+}
+
+// level L's records (and live list) from level L - 1's live list.  bid / nblocks: this job's share of the launch.
+__device__ __forceinline__ void emit_alive_body(const uint2 *__restrict__ sd, size_t n_colours, const uint32_t *__restrict__ alive_in,
+                                                uint32_t *alive_out, uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t L,
+                                                unsigned bid, unsigned nblocks) {
+  __shared__ u64c s_base, s_first;
+  __shared__ uint32_t s_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) {      // records of the earlier levels: their counters are final (earlier launches)
+    u64c before = 0;
+    for (uint32_t j = (uint32_t)lane; j < L; j += 64) before += level_counts[j];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) s_base = before;
+  }
+  const size_t n_in = L == 0 ? (n_colours > 0 ? n_colours - 1 : 0) : (size_t)level_counts[L - 1];
+  for (size_t chunk = bid; chunk * ALIVE_CHUNK < n_in; chunk += nblocks) {
+    uint32_t col[ALIVE_PER_THREAD], area[ALIVE_PER_THREAD];
+    unsigned long long m[ALIVE_PER_THREAD];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
+      const size_t i = chunk * ALIVE_CHUNK + (size_t)k * 256 + threadIdx.x;
+      const bool in = i < n_in;
+      col[k] = in ? (L == 0 ? (uint32_t)i + 1u : alive_in[i]) : 0u;      // colour 0 = uncoloured: never a lake
+    }
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
+      const uint2 v = sd[col[k]];
+      area[k] = v.x;
+      const bool lake = col[k] != 0u && v.x != 0u && v.y > L;
+      m[k] = __builtin_amdgcn_ballot_w64(lake);
+      mine += (uint32_t)__popcll(m[k]);
+    }
+    __syncthreads();      // (s_wave / s_first of the previous chunk have been read)
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    const uint32_t block_total = w0 + w1 + w2 + w3;
+    if (block_total == 0) continue;            // workgroup uniform
+    if (threadIdx.x == 0) s_first = atomicAdd(level_counts + L, (u64c)block_total);
+    __syncthreads();
+    u64c rel = s_first + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);      // position inside the level
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
+      if ((m[k] >> lane) & 1ull) {
+        const u64c r = rel + (u64c)__popcll(m[k] & ((1ull << lane) - 1ull));
+        alive_out[r] = col[k];
+        const u64c p = s_base + r;
+        if (p < cap) {
+          lakes[2 * p] = (uint64_t)col[k];
+          lakes[2 * p + 1] = (uint64_t)area[k];
+        }
+      }
+      rel += (u64c)__popcll(m[k]);
+    }
+  }
+}
+
+// the unions of `level` (sd[c].y = level for every root they hook) and, side by side, the records of level - 1
+__global__ __launch_bounds__(256) void k_union_emit_alive(const uint2 *__restrict__ edge_items, const u64c *__restrict__ range, unsigned union_blocks,
+                                                          uint32_t *parent, uint32_t *hooked, uint32_t *hooked_count, uint2 *sd, uint32_t level,
+                                                          size_t n_colours, const uint32_t *__restrict__ alive_in, uint32_t *alive_out,
+                                                          uint64_t *lakes, size_t cap, u64c *level_counts) {
+  if (blockIdx.x < union_blocks) {
+    edge_items += range[0];
+    const size_t n = (size_t)(range[1] - range[0]);
+    const size_t step = (size_t)union_blocks * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+      const uint2 e = edge_items[i];
+      const uint32_t lost = uf_union(parent, e.x, e.y);
+      if (lost != 0xFFFFFFFFu) {
+        hooked[atomicAdd(hooked_count, 1u)] = lost;
+        sd[lost].y = level;
+      }
+    }
+  } else if (level > 0) {
+    emit_alive_body(sd, n_colours, alive_in, alive_out, lakes, cap, level_counts, level - 1, blockIdx.x - union_blocks, gridDim.x - union_blocks);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emit_alive(const uint2 *__restrict__ sd, size_t n_colours, const uint32_t *__restrict__ alive_in,
+                                                    uint32_t *alive_out, uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t L) {
+  emit_alive_body(sd, n_colours, alive_in, alive_out, lakes, cap, level_counts, L, blockIdx.x, gridDim.x);
+}
+
+// alive: two lists of n_colours words; level L reads alive[(L + 1) & 1] and writes alive[L & 1]
+hipError_t union_emit_alive(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
+                            uint32_t *hooked_count, uint2 *sd, uint32_t level, size_t n_colours, uint32_t *alive, unsigned emit_grid,
+                            uint64_t *lakes, size_t cap, u64c *level_counts) {
+  const uint32_t L = level - 1;      // the level whose records ride along (level > 0)
+  k_union_emit_alive<<<union_grid + (level > 0 ? emit_grid : 0u), 256, 0, s>>>(edge_items, range, union_grid, parent, hooked, hooked_count, sd, level,
+                                                                             n_colours, alive + (size_t)((L + 1) & 1u) * n_colours,
+                                                                             alive + (size_t)(L & 1u) * n_colours, lakes, cap, level_counts);
+  return hipGetLastError();
+}
+
+hipError_t emit_alive(hipStream_t s, const uint2 *sd, size_t n_colours, uint32_t *alive, unsigned emit_grid, uint64_t *lakes, size_t cap,
+                      u64c *level_counts, uint32_t L) {
+  k_emit_alive<<<emit_grid, 256, 0, s>>>(sd, n_colours, alive + (size_t)((L + 1) & 1u) * n_colours, alive + (size_t)(L & 1u) * n_colours, lakes, cap,
+                                         level_counts, L);
+  return hipGetLastError();
+}
+
+// k_fold_and_add on sd[].x, for planes where a level brings hundreds of thousands of pixels to a handful of lakes: a wave adds
+// up the RUN of items that go to one root (the common case late in the flood: all of them) over its four steps and adds once,
+// and the four waves of a workgroup that end on the same root add once together -- a same-address atomic retires every ~12 ns,
+// and one per wave and step was 49 of the kernel's 74 us per level at 8192^2.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {      // total of v over the wave, in every lane
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
+
+constexpr int FOLD_STEPS = 4;      // items per thread of the counting half
+
+__global__ __launch_bounds__(256) void k_fold_and_add_sd(const uint32_t *__restrict__ hooked, const uint32_t *__restrict__ hooked_count,
+                                                         const uint32_t *__restrict__ px_items, const u64c *__restrict__ range,
+                                                         uint32_t *parent, uint2 *sd) {
+  __shared__ uint32_t s_root[4], s_cnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned half = gridDim.x / 2;
+  uint32_t *size = reinterpret_cast<uint32_t *>(sd);      // area of colour c: size[2 c]
+  if (blockIdx.x >= half) {
+    // folds: the areas of the roots hooked at this level go to the roots they ended under
+    const unsigned bid = blockIdx.x - half;
+    const uint32_t nh = *hooked_count;
+    for (size_t base = (size_t)bid * 256; base < nh; base += (size_t)half * 256) {
+      const size_t i = base + threadIdx.x;
+      const bool active = i < nh;
+      const uint32_t b = active ? hooked[i] : 0u;
+      const uint32_t area = active ? size[2 * (size_t)b] : 0u;
+      const uint32_t r = active && area ? uf_find(parent, b) : 0xFFFFFFFFu;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(r != 0xFFFFFFFFu);
+      for (int round = 0; round < 2 && todo != 0; ++round) {      // the one or two lakes that swallow most of the others
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
+        const bool same = r == r0;
+        const uint32_t sum = wave_sum_u32(same ? area : 0u);
+        if (lane == leader) atomicAdd(&size[2 * (size_t)r0], sum);
+        todo &= ~__builtin_amdgcn_ballot_w64(same);
+      }
+      if ((todo >> lane) & 1ull) atomicAdd(&size[2 * (size_t)r], area);
+    }
+    return;
+  }
+  // arrivals: a workgroup takes 256 * FOLD_STEPS consecutive items
+  const u64c first = range[0];
+  const size_t n = (size_t)(range[1] - first);
+  px_items += first;
+  for (size_t base = (size_t)blockIdx.x * (256 * FOLD_STEPS); base < n; base += (size_t)half * (256 * FOLD_STEPS)) {
+    uint32_t run_root = 0xFFFFFFFFu, run_cnt = 0;      // wave uniform
+#pragma unroll
+    for (int st = 0; st < FOLD_STEPS; ++st) {
+      const size_t i = base + (size_t)st * 256 + threadIdx.x;
+      const bool active = i < n;
+      const uint32_t r = active ? uf_find(parent, px_items[i]) : 0xFFFFFFFFu;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+      if (todo != 0) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(active && r == r0);
+        if (r0 != run_root) {
+          if (run_cnt && lane == 0) atomicAdd(&size[2 * (size_t)run_root], run_cnt);
+          run_root = r0;
+          run_cnt = 0;
+        }
+        run_cnt += (uint32_t)__popcll(same);
+        todo &= ~same;
+        // what is left (early levels: every lane another lake): two more rounds of leader election, then one add per lane
+        for (int round = 0; round < 2 && todo != 0; ++round) {
+          const int l2 = (int)__builtin_ctzll(todo);
+          const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)r, l2);
+          const unsigned long long s2 = __builtin_amdgcn_ballot_w64(active && r == r2);
+          if (lane == l2) atomicAdd(&size[2 * (size_t)r2], (uint32_t)__popcll(s2));
+          todo &= ~s2;
+        }
+        if ((todo >> lane) & 1ull) atomicAdd(&size[2 * (size_t)r], 1u);
+      }
+    }
+    // the waves' runs: one add per distinct root of the workgroup (all four equal late in the flood)
+    __syncthreads();
+    if (lane == 0) { s_root[wave] = run_cnt ? run_root : 0xFFFFFFFFu; s_cnt[wave] = run_cnt; }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_root[threadIdx.x] != 0xFFFFFFFFu) {
+      bool first_of_its_root = true;
+      uint32_t total = 0;
+      for (int k = 0; k < 4; ++k)
+        if (s_root[k] == s_root[threadIdx.x]) { if (k < (int)threadIdx.x) first_of_its_root = false; total += s_cnt[k]; }
+      if (first_of_its_root) atomicAdd(&size[2 * (size_t)s_root[threadIdx.x]], total);
+    }
+  }
+}
+
+hipError_t fold_and_add_sd(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items, const u64c *range,
+                           unsigned grid, uint32_t *parent, uint2 *sd) {
+  k_fold_and_add_sd<<<2 * grid, 256, 0, s>>>(hooked, hooked_count, px_items, range, parent, sd);
   return hipGetLastError();
 }
 

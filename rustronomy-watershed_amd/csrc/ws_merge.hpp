@@ -59,6 +59,17 @@ hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range,
                       uint32_t *hooked_count, uint32_t *death, uint32_t level, const uint32_t *size, size_t n_colours, uint64_t *lakes,
                       size_t cap, u64c *level_counts);
 
+// merging transform_to_list at size (ws_merge.hip, "records from the list of LIVE lakes"): sd[c] = (area, death level);
+// alive: two lists of n_colours words; level L reads alive[(L + 1) & 1] (level 0: every colour) and writes alive[L & 1]
+hipError_t sd_init(hipStream_t s, uint2 *sd, size_t n);      // (0, 0xFFFFFFFF)
+hipError_t union_emit_alive(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
+                            uint32_t *hooked_count, uint2 *sd, uint32_t level, size_t n_colours, uint32_t *alive, unsigned emit_grid,
+                            uint64_t *lakes, size_t cap, u64c *level_counts);
+hipError_t emit_alive(hipStream_t s, const uint2 *sd, size_t n_colours, uint32_t *alive, unsigned emit_grid, uint64_t *lakes, size_t cap,
+                      u64c *level_counts, uint32_t L);
+hipError_t fold_and_add_sd(hipStream_t s, const uint32_t *hooked, const uint32_t *hooked_count, const uint32_t *px_items, const u64c *range,
+                           unsigned grid, uint32_t *parent, uint2 *sd);
+
 // merging across the row blocks of a tiled field: joins the touching colours of one block (seam pairs to its halo rows
 // included; row0 = field row of the block's first local row, H = rows of the whole field), and the (colour, root) pairs
 // of the block's boundary and halo rows (4 * w of them) that the ranks exchange
