@@ -162,6 +162,11 @@ int ws_ctx_set_batch_pixel_limit(ws_ctx *ctx, size_t max_px);
  * bands and strips instead of a second pass over every tile (same labels either way).  0 restores the
  * default, 2^24: smaller planes are bound by launch gaps and gain nothing.  (Tests lower it to cover the path on small planes.) */
 int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
+/* The merging transform_to_list of a seed list with at least this many entries writes every level's lake records from the
+ * list of the lakes alive at the level before, instead of looking at every colour at every level (same records, the order
+ * inside a level differs).  0 restores the default, 2^20: fewer colours are bound by launch latency and gain nothing.
+ * (Tests lower it to cover the form on small planes.) */
+int ws_ctx_set_live_list_min_colours(ws_ctx *ctx, size_t min_colours);
 
 /* TransformBuilder::build_segmenting / build_merging validation (lib.rs:999-1004, 1026-1030). */
 int ws_options_default(ws_options *out);          /* lib.rs:936-946: max 254, no edge correction */
@@ -178,6 +183,13 @@ int ws_find_local_minima(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, si
 int ws_segment(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
                const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
                uint64_t *out_labels);
+
+/* The same with the labels as the device holds them, uint32_t (colours are 1..=n_seeds < 2^32): half the bytes of the
+ * usize plane over PCIe (8192^2: 256 MiB instead of 512 -- the transform itself is 0.56 ms of the 13.7 ms ws_segment takes there,
+ * the rest is the link at its 53 GB/s).  For callers that can hold u32 labels; not what transform() returns. */
+int ws_segment_u32(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+                   const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
+                   uint32_t *out_labels);
 
 /* Watershed::transform_with_hook for SegmentingWatershed (lib.rs:1638-1808): cb is called
  * after every level 0..=max with the label plane of that level; transform_history

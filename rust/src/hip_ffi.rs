@@ -129,6 +129,7 @@ extern "C" {
     pub fn ws_ctx_synchronize(ctx: *mut ws_ctx) -> c_int;
     pub fn ws_ctx_set_batch_pixel_limit(ctx: *mut ws_ctx, max_px: usize) -> c_int;
     pub fn ws_ctx_set_seam_repair_min_pixels(ctx: *mut ws_ctx, min_px: usize) -> c_int;
+    pub fn ws_ctx_set_live_list_min_colours(ctx: *mut ws_ctx, min_colours: usize) -> c_int;
     pub fn ws_options_default(out: *mut ws_options) -> c_int;
     pub fn ws_options_validate(opt: *const ws_options) -> c_int;
 
@@ -137,6 +138,8 @@ extern "C" {
         out_rc: *mut u64, cap: usize, n_found: *mut usize) -> c_int;
     pub fn ws_segment(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
         seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, out_labels: *mut u64) -> c_int;
+    pub fn ws_segment_u32(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, out_labels: *mut u32) -> c_int;
     pub fn ws_segment_with_hook(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
         seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, cb: ws_level_cb, user: *mut c_void,
         out_labels: *mut u64) -> c_int;

@@ -93,10 +93,12 @@ SIGNATURES = {
     "ws_ctx_synchronize": (ctypes.c_int, [vp]),
     "ws_ctx_set_batch_pixel_limit": (ctypes.c_int, [vp, sz]),
     "ws_ctx_set_seam_repair_min_pixels": (ctypes.c_int, [vp, sz]),
+    "ws_ctx_set_live_list_min_colours": (ctypes.c_int, [vp, sz]),
     "ws_options_default": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_options_validate": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_find_local_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
     "ws_segment": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_segment_u32": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_segment_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
     "ws_merge_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
     "ws_transform_to_list": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz,

@@ -280,6 +280,14 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *c, size_t min_px) {
   return WS_OK;
 }
 
+int ws_ctx_set_live_list_min_colours(ws_ctx *c, size_t min_colours) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c) return WS_ERR_BAD_ARG;
+  c->live_list_min = min_colours == 0 ? (size_t)1 << 20 : min_colours;
+  ++c->buffer_generation;      // captured level graphs hold the launches of the other form
+  return WS_OK;
+}
+
 int ws_ctx_synchronize(ws_ctx *c) {
   if (!c) return WS_ERR_BAD_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

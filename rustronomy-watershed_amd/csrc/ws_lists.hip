@@ -71,7 +71,8 @@ struct FusedEmit {
   bool on = false;
   size_t n_colours = 0, cap = 0;
   uint64_t *lakes = nullptr;
-  unsigned emit_grid = 0;      // workgroups of the live-list walk (ws_merge.hip: records from the list of LIVE lakes)
+  bool live = false;           // many colours: records from the list of LIVE lakes (ws_merge.hip) instead of a look at every colour per level
+  unsigned emit_grid = 0;      // workgroups of the live-list walk
 };
 template <class F>
 int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_sizes, unsigned grid, F per_level, const FusedEmit &fe = FusedEmit()) {
@@ -81,11 +82,22 @@ int level_range(ws_ctx *c, uint32_t l0, uint32_t l1, bool merging, bool want_siz
   const uint32_t *px_items = (const uint32_t *)c->px_items.p;
   const uint2 *edge_items = (const uint2 *)c->edge_items.p;
   for (uint32_t l = l0; l < l1; ++l) {
+    if (fe.on && !fe.live) {
+      HIP_TRY(c, union_emit(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, hooked, hooked_count + l, (uint32_t *)c->uf_death.p, l,
+                            size, fe.n_colours, fe.lakes, fe.cap, mf + MF_LAKE_COUNT));
+      HIP_TRY(c, fold_and_add_ranged(c->stream, hooked, hooked_count + l, px_items, mf + MF_OFF_PX + l, grid, parent, size));
+      int rc = per_level(l);
+      if (rc) return rc;
+      continue;
+    }
     if (fe.on) {
-      // lists without a hook: areas and death levels live side by side in uf_sd, level l - 1's records are found among level
+      // lists without a hook, many colours: areas and death levels live side by side in uf_sd, level l - 1's records are found among level
       // l - 2's live lakes, and the arrivals of a level are added up per wave and workgroup before they reach a lake's counter
+      static const bool split = tuning_env("WS_TOLIST_SPLIT") != nullptr;      // A/B knob for tools/: the two jobs as launches of their own
       HIP_TRY(c, union_emit_alive(c->stream, edge_items, mf + MF_OFF_ED + l, grid, parent, hooked, hooked_count + l, (uint2 *)c->uf_sd.p, l,
-                                  fe.n_colours, (uint32_t *)c->alive.p, fe.emit_grid, fe.lakes, fe.cap, mf + MF_LAKE_COUNT));
+                                  fe.n_colours, (uint32_t *)c->alive.p, split ? 0u : fe.emit_grid, fe.lakes, fe.cap, mf + MF_LAKE_COUNT));
+      if (split && l > 0)
+        HIP_TRY(c, emit_alive(c->stream, (const uint2 *)c->uf_sd.p, fe.n_colours, (uint32_t *)c->alive.p, fe.emit_grid, fe.lakes, fe.cap, mf + MF_LAKE_COUNT, l - 1));
       HIP_TRY(c, fold_and_add_sd(c->stream, hooked, hooked_count + l, px_items, mf + MF_OFF_PX + l, grid, parent, (uint2 *)c->uf_sd.p));
       int rc = per_level(l);
       if (rc) return rc;
@@ -137,9 +149,14 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   const uint32_t *keys = (const uint32_t *)c->keys.p;
   // every buffer first, so that nothing moves once launches (or captured graphs) hold its address
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
-  if (merging && want_list && !cb) {      // the live-list form of the lists (FusedEmit below)
+  // Planes with a million colours and more (4096^2 random fields on) write their lake records from the list of the lakes
+  // still alive, not from a look at every colour at every level (8192^2: 66.8 -> 20.5 ms); below that the per-level
+  // launches are latency-bound either way and the older, shorter kernels win (1024^2, the core_bench shape: 3.8 against 5.0 ms).
+  // (ws_ctx_set_live_list_min_colours: tests lower the threshold to cover the form on small planes)
+  const bool live_lists = merging && want_list && !cb && n_seeds >= c->live_list_min;
+  if (live_lists) {
     if ((rc = ensure(c, c->uf_sd, (n_seeds + 1) * sizeof(uint2)))) return rc;
-    if ((rc = ensure(c, c->alive, 2 * (n_seeds + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->alive, 2 * alive_list_words(n_seeds + 1) * sizeof(uint32_t)))) return rc;
   }
   if (want_list && !dev && (rc = ensure(c, c->lakes, (cap ? cap : 1) * 2 * sizeof(uint64_t)))) return rc;
   uint64_t *d_records = dev ? (uint64_t *)dev->d_lakes : (uint64_t *)c->lakes.p;      // (colour, area) pairs
@@ -156,9 +173,12 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   FusedEmit fe;
   fe.on = merging && want_list && !cb;
   fe.n_colours = n_seeds + 1; fe.cap = cap; fe.lakes = d_records;
-  if (fe.on) {
+  fe.live = live_lists;
+  if (fe.on && fe.live) {
     fe.emit_grid = (unsigned)std::min<size_t>(std::max<size_t>((n_seeds + 4095) / 4096, 1), 1024);
     HIP_TRY(c, sd_init(c->stream, (uint2 *)c->uf_sd.p, n_seeds + 1));      // no pixels yet, every colour a root
+  } else if (fe.on) {
+    HIP_TRY(c, hipMemsetAsync(c->uf_death.p, 0xFF, (n_seeds + 1) * sizeof(uint32_t), c->stream));      // every colour a root
   }
   auto per_level = [&](uint32_t l) -> int {
     if (want_list && !fe.on)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
@@ -221,8 +241,12 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   }
   const uint32_t n_groups = (levels + LIST_GROUP - 1) / LIST_GROUP;
   if (fe.on) {      // the last level's records; and a marker behind them: in this mode a group's last level is complete one launch later
-    HIP_TRY(c, emit_alive(c->stream, (const uint2 *)c->uf_sd.p, n_seeds + 1, (uint32_t *)c->alive.p, fe.emit_grid, d_records, cap, mf + MF_LAKE_COUNT,
-                          levels - 1));
+    if (fe.live)
+      HIP_TRY(c, emit_alive(c->stream, (const uint2 *)c->uf_sd.p, n_seeds + 1, (uint32_t *)c->alive.p, fe.emit_grid, d_records, cap, mf + MF_LAKE_COUNT,
+                            levels - 1));
+    else
+      HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, d_records, cap, mf + MF_LAKE_COUNT, levels - 1,
+                            (const uint32_t *)c->uf_death.p));
     HIP_TRY(c, hipEventRecord(c->kern_ev[n_groups], c->stream));
   }
 

@@ -82,51 +82,65 @@ __device__ __forceinline__ bool interior(int y, int x, int H, int W) {
   return y >= 1 && y < H - 1 && x >= 1 && x < W - 1;
 }
 
+// Loads first, unconditional and on clamped addresses (a load under a data-dependent branch is waited for before the next is
+// issued: 24 dependent round trips per thread in the first form of this function), predicates afterwards.  With W % 4 == 0 the
+// four pixels and the four below them are 16-byte loads.
+typedef uint32_t u32x4_m __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void gather_items(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
                                              int H, int W, int y, int x0, PixelItems &it) {
+  uint32_t kp[5], lp[5], kd[4], ld[4];      // the row's pixels x0 .. x0 + 4 and the pixels below x0 .. x0 + 3
+  const int yd = min(y + 1, H - 1);
+  if ((W & 3) == 0 && x0 + 3 < W) {
+    const size_t p = (size_t)y * W + x0, q = (size_t)yd * W + x0;
+    const u32x4_m a = *reinterpret_cast<const u32x4_m *>(keys + p), b = *reinterpret_cast<const u32x4_m *>(labels + p);
+    const u32x4_m c = *reinterpret_cast<const u32x4_m *>(keys + q), d = *reinterpret_cast<const u32x4_m *>(labels + q);
+    const size_t pr = (size_t)y * W + min(x0 + 4, W - 1);
+    kp[4] = keys[pr]; lp[4] = labels[pr];
+    kp[0] = a.x; kp[1] = a.y; kp[2] = a.z; kp[3] = a.w;
+    lp[0] = b.x; lp[1] = b.y; lp[2] = b.z; lp[3] = b.w;
+    kd[0] = c.x; kd[1] = c.y; kd[2] = c.z; kd[3] = c.w;
+    ld[0] = d.x; ld[1] = d.y; ld[2] = d.z; ld[3] = d.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const size_t p = (size_t)y * W + min(x0 + k, W - 1);
+      kp[k] = keys[p]; lp[k] = labels[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t q = (size_t)yd * W + min(x0 + k, W - 1);
+      kd[k] = keys[q]; ld[k] = labels[q];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     it.px_lvl[k] = it.er_lvl[k] = it.ed_lvl[k] = 0xFFFFFFFFu;
     const int x = x0 + k;
-    if (x >= W) continue;
-    const size_t p = (size_t)y * W + x;
-    const uint32_t kp = keys[p];
-    if (kp == KEY_INF) continue;                       // uncoloured pixels carry no lake
-    const uint32_t lp = labels[p], vp = kp >> 24;
-    it.px_lvl[k] = vp;
-    it.px_col[k] = lp;
+    const bool here = x < W && kp[k] != KEY_INF;            // uncoloured pixels carry no lake
+    const uint32_t vp = kp[k] >> 24;
+    if (here) { it.px_lvl[k] = vp; it.px_col[k] = lp[k]; }
     const bool ip = interior(y, x, H, W);
-    if (x + 1 < W) {
-      const uint32_t kq = keys[p + 1];
-      if (kq != KEY_INF) {
-        const uint32_t lq = labels[p + 1];
-        // find_merge only sees pairs around a 3x3 window centre (lib.rs:411-434)
-        if (lq != lp && (ip || interior(y, x + 1, H, W))) {
-          it.er_lvl[k] = max(vp, kq >> 24);
-          it.er[k] = make_uint2(lp, lq);
-        }
-      }
+    // find_merge only sees pairs around a 3x3 window centre (lib.rs:411-434)
+    if (here && x + 1 < W && kp[k + 1] != KEY_INF && lp[k + 1] != lp[k] && (ip || interior(y, x + 1, H, W))) {
+      it.er_lvl[k] = max(vp, kp[k + 1] >> 24);
+      it.er[k] = make_uint2(lp[k], lp[k + 1]);
     }
-    if (y + 1 < H) {
-      const uint32_t kq = keys[p + W];
-      if (kq != KEY_INF) {
-        const uint32_t lq = labels[p + W];
-        if (lq != lp && (ip || interior(y + 1, x, H, W))) {
-          it.ed_lvl[k] = max(vp, kq >> 24);
-          it.ed[k] = make_uint2(lp, lq);
-        }
-      }
+    if (here && y + 1 < H && kd[k] != KEY_INF && ld[k] != lp[k] && (ip || interior(y + 1, x, H, W))) {
+      it.ed_lvl[k] = max(vp, kd[k] >> 24);
+      it.ed[k] = make_uint2(lp[k], ld[k]);
     }
   }
 }
 
-// A workgroup takes SEG_RUN consecutive row segments (one per step), not one: the 512 level counters are hit once per
+// A workgroup takes SEG_RUN consecutive row segments of a large plane (one per step), not one: the 512 level counters are hit once per
 // workgroup and level, and with a workgroup per 1024 pixels those same-address atomics (~12 ns each) WERE the kernel --
 // 8192^2: 33 M of them on 512 words, 1.4 ms for 0.5 GB of reads.
-constexpr int SEG_RUN = 16;
+constexpr int SEG_RUN_MAX = 16;
+static int seg_run_for(size_t total) { return (int)std::min<size_t>(std::max<size_t>(total / 4096, 1), SEG_RUN_MAX); }      // small planes keep a workgroup per segment
 
 __global__ __launch_bounds__(256) void k_level_hist(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
-                                                    int H, int W, int segs, u64c *hist_px, u64c *hist_edge) {
+                                                    int H, int W, int segs, int SEG_RUN, u64c *hist_px, u64c *hist_edge) {
   __shared__ uint32_t s_px[NLEVELS], s_ed[NLEVELS];
   s_px[threadIdx.x] = 0;
   s_ed[threadIdx.x] = 0;
@@ -155,7 +169,8 @@ hipError_t level_hist(hipStream_t s, const uint32_t *keys, const uint32_t *label
   if (h == 0 || w == 0) return hipSuccess;
   const int segs = (w + MSEG - 1) / MSEG;
   const size_t total = (size_t)h * segs;
-  k_level_hist<<<(unsigned)((total + SEG_RUN - 1) / SEG_RUN), 256, 0, s>>>(keys, labels, h, w, segs, hist_px, hist_edge);
+  const int run = seg_run_for(total);
+  k_level_hist<<<(unsigned)((total + run - 1) / run), 256, 0, s>>>(keys, labels, h, w, segs, run, hist_px, hist_edge);
   return hipGetLastError();
 }
 
@@ -189,7 +204,7 @@ hipError_t level_offsets(hipStream_t s, const u64c *hist_px, const u64c *hist_ed
 // Two walks over the workgroup's SEG_RUN segments: the first counts its items per level in LDS, then ONE reservation per
 // (workgroup, level), then the second walk gathers the items again (L2 still holds them) and writes them behind LDS cursors.
 __global__ __launch_bounds__(256) void k_level_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ labels,
-                                                       int H, int W, int segs, u64c *cursor_px, u64c *cursor_edge,
+                                                       int H, int W, int segs, int SEG_RUN, u64c *cursor_px, u64c *cursor_edge,
                                                        uint32_t *px_items, uint2 *edge_items) {
   __shared__ uint32_t s_px[NLEVELS], s_ed[NLEVELS];
   __shared__ u64c s_bpx[NLEVELS], s_bed[NLEVELS];
@@ -248,7 +263,8 @@ hipError_t level_scatter(hipStream_t s, const uint32_t *keys, const uint32_t *la
   if (h == 0 || w == 0) return hipSuccess;
   const int segs = (w + MSEG - 1) / MSEG;
   const size_t total = (size_t)h * segs;
-  k_level_scatter<<<(unsigned)((total + SEG_RUN - 1) / SEG_RUN), 256, 0, s>>>(keys, labels, h, w, segs, cursor_px, cursor_edge, px_items, edge_items);
+  const int run = seg_run_for(total);
+  k_level_scatter<<<(unsigned)((total + run - 1) / run), 256, 0, s>>>(keys, labels, h, w, segs, run, cursor_px, cursor_edge, px_items, edge_items);
   return hipGetLastError();
 }
 
@@ -485,37 +501,54 @@ __device__ __forceinline__ void emit_alive_body(const uint2 *__restrict__ sd, si
     if (lane == 0) s_base = before;
   }
   const size_t n_in = L == 0 ? (n_colours > 0 ? n_colours - 1 : 0) : (size_t)level_counts[L - 1];
+  // Candidates are dealt out lane by lane (slab k of a chunk = 256 consecutive candidates: a wave's loads and its sd gathers
+  // are coalesced while the list is sorted) and the survivors KEEP THEIR ORDER inside the chunk (chunks draw their tickets in
+  // about the order of their indices), so the list stays nearly sorted by colour from level to level.  (Written out in
+  // (wave, slab, lane) order the list was reshuffled at every level and level 50's gathers -- 4 M live lakes -- took twice as
+  // long as level 0's 7.3 M sequential ones; sixteen CONSECUTIVE candidates per thread kept the order but made every load a
+  // 64-line gather: 97 us for level 0 instead of 40.)
+  __shared__ uint32_t s_cnt[ALIVE_PER_THREAD][4];
   for (size_t chunk = bid; chunk * ALIVE_CHUNK < n_in; chunk += nblocks) {
     uint32_t col[ALIVE_PER_THREAD], area[ALIVE_PER_THREAD];
     unsigned long long m[ALIVE_PER_THREAD];
-    uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
       const size_t i = chunk * ALIVE_CHUNK + (size_t)k * 256 + threadIdx.x;
-      const bool in = i < n_in;
-      col[k] = in ? (L == 0 ? (uint32_t)i + 1u : alive_in[i]) : 0u;      // colour 0 = uncoloured: never a lake
+      col[k] = i < n_in ? (L == 0 ? (uint32_t)i + 1u : alive_in[i]) : 0u;      // colour 0 = uncoloured: never a lake
     }
 #pragma unroll
     for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
       const uint2 v = sd[col[k]];
       area[k] = v.x;
-      const bool lake = col[k] != 0u && v.x != 0u && v.y > L;
-      m[k] = __builtin_amdgcn_ballot_w64(lake);
-      mine += (uint32_t)__popcll(m[k]);
+      m[k] = __builtin_amdgcn_ballot_w64(col[k] != 0u && v.x != 0u && v.y > L);
     }
-    __syncthreads();      // (s_wave / s_first of the previous chunk have been read)
-    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();      // (s_cnt / s_first of the previous chunk have been read)
+    if (lane < ALIVE_PER_THREAD) {
+      unsigned long long mk = m[0];
+#pragma unroll
+      for (int k = 1; k < ALIVE_PER_THREAD; ++k) mk = lane == k ? m[k] : mk;
+      s_cnt[lane][wave] = (uint32_t)__popcll(mk);
+    }
     __syncthreads();
-    const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-    const uint32_t block_total = w0 + w1 + w2 + w3;
+    // exclusive prefix over (slab, wave) in that order: where this wave's survivors of slab k start
+    uint32_t start[ALIVE_PER_THREAD], run = 0;
+#pragma unroll
+    for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w == wave) start[k] = run;
+        run += s_cnt[k][w];
+      }
+    }
+    const uint32_t block_total = run;
     if (block_total == 0) continue;            // workgroup uniform
     if (threadIdx.x == 0) s_first = atomicAdd(level_counts + L, (u64c)block_total);
     __syncthreads();
-    u64c rel = s_first + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);      // position inside the level
+    const u64c first = s_first;
 #pragma unroll
     for (int k = 0; k < ALIVE_PER_THREAD; ++k) {
       if ((m[k] >> lane) & 1ull) {
-        const u64c r = rel + (u64c)__popcll(m[k] & ((1ull << lane) - 1ull));
+        const u64c r = first + start[k] + (u64c)__popcll(m[k] & ((1ull << lane) - 1ull));      // position inside the level
         alive_out[r] = col[k];
         const u64c p = s_base + r;
         if (p < cap) {
@@ -523,7 +556,6 @@ __device__ __forceinline__ void emit_alive_body(const uint2 *__restrict__ sd, si
           lakes[2 * p + 1] = (uint64_t)area[k];
         }
       }
-      rel += (u64c)__popcll(m[k]);
     }
   }
 }
@@ -555,20 +587,24 @@ __global__ __launch_bounds__(256) void k_emit_alive(const uint2 *__restrict__ sd
   emit_alive_body(sd, n_colours, alive_in, alive_out, lakes, cap, level_counts, L, blockIdx.x, gridDim.x);
 }
 
-// alive: two lists of n_colours words; level L reads alive[(L + 1) & 1] and writes alive[L & 1]
+// alive: two lists of alive_list_words(n_colours) words; level L reads list (L + 1) & 1 and writes list L & 1
+size_t alive_list_words(size_t n_colours) { return (n_colours + 3) & ~(size_t)3; }      // 16-byte aligned lists
+
 hipError_t union_emit_alive(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
                             uint32_t *hooked_count, uint2 *sd, uint32_t level, size_t n_colours, uint32_t *alive, unsigned emit_grid,
                             uint64_t *lakes, size_t cap, u64c *level_counts) {
   const uint32_t L = level - 1;      // the level whose records ride along (level > 0)
+  const size_t stride = alive_list_words(n_colours);
   k_union_emit_alive<<<union_grid + (level > 0 ? emit_grid : 0u), 256, 0, s>>>(edge_items, range, union_grid, parent, hooked, hooked_count, sd, level,
-                                                                             n_colours, alive + (size_t)((L + 1) & 1u) * n_colours,
-                                                                             alive + (size_t)(L & 1u) * n_colours, lakes, cap, level_counts);
+                                                                             n_colours, alive + (size_t)((L + 1) & 1u) * stride,
+                                                                             alive + (size_t)(L & 1u) * stride, lakes, cap, level_counts);
   return hipGetLastError();
 }
 
 hipError_t emit_alive(hipStream_t s, const uint2 *sd, size_t n_colours, uint32_t *alive, unsigned emit_grid, uint64_t *lakes, size_t cap,
                       u64c *level_counts, uint32_t L) {
-  k_emit_alive<<<emit_grid, 256, 0, s>>>(sd, n_colours, alive + (size_t)((L + 1) & 1u) * n_colours, alive + (size_t)(L & 1u) * n_colours, lakes, cap,
+  const size_t stride = alive_list_words(n_colours);
+  k_emit_alive<<<emit_grid, 256, 0, s>>>(sd, n_colours, alive + (size_t)((L + 1) & 1u) * stride, alive + (size_t)(L & 1u) * stride, lakes, cap,
                                          level_counts, L);
   return hipGetLastError();
 }

@@ -60,8 +60,9 @@ hipError_t union_emit(hipStream_t s, const uint2 *edge_items, const u64c *range,
                       size_t cap, u64c *level_counts);
 
 // merging transform_to_list at size (ws_merge.hip, "records from the list of LIVE lakes"): sd[c] = (area, death level);
-// alive: two lists of n_colours words; level L reads alive[(L + 1) & 1] (level 0: every colour) and writes alive[L & 1]
+// alive: two lists of alive_list_words(n_colours) words; level L reads list (L + 1) & 1 (level 0: every colour) and writes list L & 1
 hipError_t sd_init(hipStream_t s, uint2 *sd, size_t n);      // (0, 0xFFFFFFFF)
+size_t alive_list_words(size_t n_colours);                   // words of ONE of the two live lists
 hipError_t union_emit_alive(hipStream_t s, const uint2 *edge_items, const u64c *range, unsigned union_grid, uint32_t *parent, uint32_t *hooked,
                             uint32_t *hooked_count, uint2 *sd, uint32_t level, size_t n_colours, uint32_t *alive, unsigned emit_grid,
                             uint64_t *lakes, size_t cap, u64c *level_counts);

@@ -134,7 +134,35 @@ constexpr uint32_t ST_SELF = 0x80000000u;        // (word 0) the tile stopped at
 constexpr uint32_t ST_PASS = 0x3FFFFFFFu;
 constexpr uint32_t RX_CAND = 64;      // candidates a workgroup collects before it hands them in (k_relax, append_flush)
 // tile_list header: [0 .. 3] list lengths and [4 .. 7] entry tickets of pass & 3 (a launch clears the words of pass + 2)
-constexpr uint32_t RL_HDR = 8;
+constexpr uint32_t RL_HDR = 16;
+// ... and, for the persistent tile-queue pass (k_relax, PERSIST): [8] tiles queued or running, [9] "the queue has run dry" (1) or
+// "a worker ran out of its time budget" (2), [10] tile runs (diagnostics)
+constexpr uint32_t RLQ_PENDING = 8, RLQ_DONE = 9, RLQ_RUNS = 10;
+// A worker gives up -- and tells the others to -- when the launch has lasted this long (s_memrealtime ticks of 10 ns): no spin
+// of this kernel can outlive it, whatever goes wrong with the queue.  What is left undone is work for the passes that follow.
+constexpr unsigned long long RLQ_BUDGET_TICKS = 5000000ull;      // 50 ms; a smooth 8192^2 map needs 3
+
+// Stamp accesses of the persistent pass: tiles hand their border pixels to each other INSIDE a launch, across CUs and XCDs,
+// so every stamp is stored write-through and loaded past L1 at agent scope (global_store / global_load ... sc1), 8 bytes a
+// time (the widest agent-scope access HIP's atomics offer; MI355X_MICROARCH.md, inter-workgroup visibility).
+template <bool COH>
+__device__ __forceinline__ u32x4_t ld_stamps4(const uint32_t *p) {
+  if (!COH) return *reinterpret_cast<const u32x4_t *>(p);
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_stamp(const uint32_t *p) {
+  if (!COH) return *p;
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ void st_stamps4(uint32_t *p, u32x4_t v) {
+  if (!COH) { *reinterpret_cast<u32x4_t *>(p) = v; return; }
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p) + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int TW, int TH>
 __device__ __forceinline__ unsigned long long relax_todo(int first, int stride, int chunk, int H, int W, int tilesX, int tilesY, int otherX,
@@ -331,7 +359,20 @@ __device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uin
   // and the checked sweep's)
 }
 
-template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false, int SEAM = 0>
+// PERSIST (the first same-grid pass of a long-range flood, relax_pass): ONE launch instead of a pass per step of the flood
+// front.  The workgroups -- all resident -- pull tiles from a queue; a tile run that changes a side that matters to a
+// neighbour, or stops at its round cap, puts that neighbour (itself) back into the queue, at once: no pass barrier, so the
+// critical path is the chain of tile runs along the flood instead of the slowest tile of each of ~180 launches.
+//   queue   a ring of (sequence number, tile) pairs in the two entry arrays of tile_list; head = the ticket word, tail = the
+//           length word of this pass; a worker draws a ticket and waits for ITS entry (the sequence number tells it from the
+//           ring's previous lap);
+//   state   one word per tile (the "queued" marks): bit 0 queued -- or, while bit 1 is set, "flagged again while running" --,
+//           bit 1 running.  A tile is in the queue at most once, and a tile flagged while it runs queues itself when it ends;
+//   end     [RLQ_PENDING] counts tiles queued or running; who brings it to zero raises [RLQ_DONE].
+// Exactness does not rest on any of this: stamps only ever fall, by relaxation steps from upper bounds (a stale read is an
+// older, larger stamp: less progress, never a wrong value), and the pass AFTER this launch runs every tile once from an
+// all-tiles list -- the flood is at its fixpoint when the ordinary passes that follow say so.
+template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false, int SEAM = 0, bool PERSIST = false>
 __global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
 const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
@@ -397,16 +438,28 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // list mode (late passes of a long-range flood): the tiles to run were compacted by k_relax_list; workgroup b takes
   // entries b, b + gridDim.x, ... -- no workgroup is launched for a tile that has nothing to do, none owns two busy ones
   uint32_t entry = blockIdx.x, n_entries = 0, first_entry = 0, runs_done = 0;
-  if (CHUNKED && use_list) {
+  // PERSIST: the queue (see above)
+  unsigned long long *q_ring = reinterpret_cast<unsigned long long *>(tile_list + RL_HDR);      // list_cap entries: (sequence + 1) << 32 | tile
+  uint32_t *q_state = tile_list + RL_HDR + 2 * (size_t)list_cap;
+  uint32_t *q_head = tile_list + 4 + (pass & 3u), *q_tail = tile_list + (pass & 3u);
+  uint32_t *q_pending = tile_list + RLQ_PENDING, *q_done = tile_list + RLQ_DONE;
+  __shared__ uint32_t s_qtile;
+  unsigned long long q_t0 = 0;
+  if (PERSIST) {
+    q_t0 = __builtin_amdgcn_s_memrealtime();
+    // whatever this launch does, the passes after it look at every tile again: tell the host that they have to run
+    if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+      pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT] = 1u;
+  } else if (CHUNKED && use_list) {
     // (the workgroup's first entry is asked for together with the list length, not after it: one memory round trip less
     // at the head of every tile run of a thin pass, which IS such a pass's length)
     first_entry = tile_list[RL_HDR + (pass & 1u) * list_cap + min(entry, list_cap - 1u)];
     n_entries = tile_list[pass & 3u];
     if (entry >= n_entries) return;
-  } else if (CHUNKED) {
+  } else if (CHUNKED && !PERSIST) {
     todo = relax_todo<TW, TH>(first, stride, chunk, H, W, tilesX, tilesY, otherX, otherY, shifted, pass, stamps_prev, read_same);
     if (todo == 0) return;
-  } else {
+  } else if (!PERSIST) {
     const int tx = first % tilesX, ty = first / tilesX;
     // (a seam whose tiles on both sides have asked for a re-run already -- pass 0 stopped at its round cap there: a smooth
     // map -- is left to them: on such maps the repair would be 64 us of sweeps that the re-runs undo)
@@ -461,6 +514,29 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     if (lane == 0) s_ncand = 0;
   };
   for (;;) {
+  uint32_t q_tile = 0;
+  if (PERSIST) {
+    if (threadIdx.x == 0) {
+      unsigned long long v = 0;
+      if (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const uint32_t my = atomicAdd(q_head, 1u);
+        unsigned long long *slot = q_ring + (my % list_cap);
+        for (;;) {
+          v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(v >> 32) == my + 1u) break;      // my entry (not one of the ring's previous lap)
+          v = 0;
+          if (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (__builtin_amdgcn_s_memrealtime() - q_t0 > RLQ_BUDGET_TICKS) { __hip_atomic_store(q_done, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if (v != 0) atomicExch(q_state + (uint32_t)v, 2u);      // queued -> running: whoever flags it from now on makes it run again
+      }
+      s_qtile = v != 0 ? (uint32_t)v + 1u : 0u;
+    }
+    __syncthreads();
+    q_tile = s_qtile;
+    if (q_tile == 0) break;      // workgroup uniform: the queue has run dry (or the time budget is spent)
+  }
   // re-derived per tile on purpose (the asm hides the value from loop-invariant hoisting): hoisted
   // per-lane addresses pushed the chunked variant over the 80-VGPR cap and into scratch
   int tid = threadIdx.x;
@@ -468,7 +544,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   const int lane = tid & 63;
   const int xl = SPLIT ? lane & 31 : lane;                                      // column block of the tile row
   const int band = SPLIT ? (tid >> 6) * 2 + (lane >> 5) : tid >> 6;             // four-row band of the tile
-  const int tile = CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[RL_HDR + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first;
+  const int tile = PERSIST ? (int)(q_tile - 1u)
+                           : (CHUNKED ? (use_list ? (int)(entry == blockIdx.x ? first_entry : tile_list[RL_HDR + (pass & 1u) * list_cap + entry]) : first + (int)__builtin_ctzll(todo) * stride) : first);
   const int tile_x = tile % tilesX, tile_y = tile / tilesX;
   const int x0 = SEAM ? tile_x * TW : tile_x * TW - (shifted ? TW / 2 : 0);
   const int y0 = SEAM == 1 ? (tile_y + 1) * SEAM_PY - SEAM_HALF : tile_y * TH - (shifted ? TH / 2 : 0);
@@ -480,7 +557,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // List mode: entries are handed out by ticket, not in strides of the grid -- tile runs last 8 to 20 us, and with a fixed
   // share a pass ended with most workgroups gone and a few still on their third tile.  The ticket for the NEXT entry is
   // drawn now and read after the run: its round trip hides behind the tile.
-  if (CHUNKED && use_list && tid == 0) s_next[runs_done & 1u] = gridDim.x + atomicAdd(&tile_list[4 + (pass & 3u)], 1u);
+  if (!PERSIST && CHUNKED && use_list && tid == 0) s_next[runs_done & 1u] = gridDim.x + atomicAdd(&tile_list[4 + (pass & 3u)], 1u);
 
   // ---- load phase ---------------------------------------------------------------------------
   uint32_t T[RX_P][RX_P], B[RX_P][RX_P], halo[RX_P];
@@ -530,11 +607,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       const int gyc = min(max(gyb + r, 0), H - 1);
-      kv[r] = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gyc * W + gxc0);
+      kv[r] = ld_stamps4<PERSIST>(ksrc + (size_t)gyc * W + gxc0);
       iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
-      halo[r] = ksrc[(size_t)gyc * W + xh];
+      halo[r] = ld_stamp<PERSIST>(ksrc + (size_t)gyc * W + xh);
     }
-    halo_row = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gy_halo * W + gxc0);
+    halo_row = ld_stamps4<PERSIST>(ksrc + (size_t)gy_halo * W + gxc0);
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       T[r][0] = kv[r].x; T[r][1] = kv[r].y; T[r][2] = kv[r].z; T[r][3] = kv[r].w;
@@ -764,7 +841,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       const int gy = gyb + r;
       if (gy >= 0 && gy < H) {
         if (full_x) {
-          *reinterpret_cast<u32x4_t *>(keys + (size_t)gy * W + gx0) = u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]};
+          st_stamps4<PERSIST>(keys + (size_t)gy * W + gx0, u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]});
         } else {
 #pragma unroll
           for (int c = 0; c < RX_P; ++c) if (gx0 + c >= 0 && gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
@@ -832,6 +909,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     stamps_cur[((size_t)(gyb / SEAM_PY) * otherX + (seam_x / SEAM_PX - 1 + (lane & 1))) * 4 + 3] = pass + 1;
     e |= 1u;
   }
+  // PERSIST: every wave's stamps have left for memory before the workgroup's barrier, and so before wave 0 flags a neighbour
+  if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (ovf) atomicExch(pf.overflow, 1u);      // never taken on sane inputs
   if (unfinished && (write_same || SEAM == 1 || chunk == 3)) e |= 32u;      // (chunk == 3: pass 0 of a seam-repair transform)
   if (e) atomicOr(&s_edges, e);
@@ -894,6 +973,42 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     }
   }
   WS_STAMP(3);
+  if (PERSIST) {
+    __syncthreads();      // thread 0's candidates (s_cand, s_ncand: the append_next block above) are there
+    if (tid < 64) {
+      const uint32_t self = (uint32_t)tile, n = s_ncand;
+      const bool mine = (uint32_t)lane < n;
+      const uint32_t cand = mine ? s_cand[lane] : 0u;
+      // idle -> queued: mine to push; queued already: nothing; running: flagged, it queues itself when it ends
+      const bool fresh = mine && atomicOr(&q_state[cand], 1u) == 0u;
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
+      const uint32_t nf = (uint32_t)__popcll(fm);
+      // my run is over: running -> idle, or -> queued if somebody (I myself, at my round cap) flagged me meanwhile
+      uint32_t again = 0;
+      if (lane == 0) again = atomicAnd(&q_state[self], ~2u) & 1u;
+      again = (uint32_t)__shfl((int)again, 0, 64);
+      const uint32_t total = nf + again;
+      if (total) {
+        uint32_t at = 0;
+        if (lane == 0) { atomicAdd(q_pending, total); at = atomicAdd(q_tail, total); }      // counted before anyone can take them
+        at = (uint32_t)__shfl((int)at, 0, 64);
+        if (fresh) {
+          const uint32_t idx = at + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+          __hip_atomic_store(q_ring + (idx % list_cap), ((unsigned long long)(idx + 1u) << 32) | cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0 && again) {
+          const uint32_t idx = at + nf;
+          __hip_atomic_store(q_ring + (idx % list_cap), ((unsigned long long)(idx + 1u) << 32) | self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (lane == 0) {
+        s_ncand = 0;
+        if (atomicSub(q_pending, 1u) == 1u) __hip_atomic_store(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nothing queued, nothing running
+        atomicAdd(tile_list + RLQ_RUNS, 1u);
+      }
+    }
+    continue;
+  }
   // next tile of the chunk: every wave is past its last read of the shared arrays (barrier above)
   if (!CHUNKED) break;
   if (use_list) {
@@ -948,11 +1063,13 @@ __global__ __launch_bounds__(256) void k_relax_list(int H, int W, int tilesX, in
 // nothing to do changes nothing.
 template <int TW, int TH, int OTW, int OTH>
 __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int tilesX, int tilesY, int oldX, int oldY, uint32_t pass,
-                                                           const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list, uint32_t list_cap) {
+                                                           const uint32_t *__restrict__ stamps_prev, uint32_t *tile_list, uint32_t list_cap,
+                                                           int persist) {
+  // persist: the list is the first filling of the persistent pass's queue (k_relax, PERSIST) -- (sequence number, tile) pairs
+  // in the ring, the tiles' state words "queued", the tiles counted in [RLQ_PENDING]; the host has zeroed ring and counters
   const int lane = threadIdx.x & 63;
   const int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) & ~63u);
   const int t = first + lane;
-  if ((uint32_t)t <= list_cap) tile_list[RL_HDR + 2 * (size_t)list_cap + t] = 0u;      // queued marks (and the dummy slot)
   bool run = false;
   if (t < tilesX * tilesY) {
     const int tx = t % tilesX, ty = t / tilesX;
@@ -965,12 +1082,28 @@ __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int til
       }
     run = run && tx * TW < W && ty * TH < H;
   }
+  if ((uint32_t)t <= list_cap) tile_list[RL_HDR + 2 * (size_t)list_cap + t] = persist && run ? 1u : 0u;      // queued marks (and the dummy slot)
   const unsigned long long todo = __builtin_amdgcn_ballot_w64(run);
   if (todo == 0) return;
   uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
+  if (lane == 0) {
+    base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
+    if (persist) atomicAdd(&tile_list[RLQ_PENDING], (uint32_t)__popcll(todo));
+  }
   base = __shfl(base, 0, 64);
-  if (run) tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + base + __popcll(todo & ((1ull << lane) - 1ull))] = (uint32_t)t;
+  const uint32_t idx = base + (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
+  if (run && persist) reinterpret_cast<unsigned long long *>(tile_list + RL_HDR)[idx] = ((unsigned long long)(idx + 1u) << 32) | (uint32_t)t;
+  else if (run) tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + idx] = (uint32_t)t;
+}
+
+// Every tile of the plane, as the list of `pass`: the pass after the persistent one looks at each of them once (a tile that
+// is at its fixpoint leaves after one checked sweep), whatever the queue did.
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void k_relax_list_all(int H, int W, int tilesX, int tilesY, uint32_t pass, uint32_t *tile_list, uint32_t list_cap) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) { tile_list[pass & 3u] = (uint32_t)(tilesX * tilesY); tile_list[4 + (pass & 3u)] = 0u; }
+  if ((uint32_t)t <= list_cap) tile_list[RL_HDR + 2 * (size_t)list_cap + t] = 0u;      // queued marks: the append protocol of the later passes starts clean
+  if (t < tilesX * tilesY) tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + t] = (uint32_t)t;      // (every tile of this grid starts inside the plane)
 }
 
 // words of scratch relax_pass wants for its tile lists
@@ -1165,8 +1298,27 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
       if (!appended) {
         // (one thread per tile and a few more: the queued marks, dummy slot included, are cleared here)
         const unsigned blocks = (unsigned)((std::max<size_t>((size_t)gx * gy, list_cap + 1) + 255) / 256);
+        // The first same-grid pass as ONE persistent launch (k_relax, PERSIST): workgroups pull tiles from a queue and a tile
+        // that changes something its neighbour must see queues that neighbour at once.  The pass after it runs every tile
+        // from an all-tiles list, so the fixpoint is certified by the ordinary machinery whatever the queue did.
+        static const bool no_persist = tuning_env("WS_RELAX_NO_PERSIST") != nullptr;      // A/B knob, tools/ only
+        const bool persist = !no_persist && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
+                             ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap;
+        if (persist) {
+          hipError_t e = hipMemsetAsync(tile_list + RL_HDR, 0, 2 * (size_t)list_cap * sizeof(uint32_t), s);      // the ring: no entry yet
+          if (e == hipSuccess) e = hipMemsetAsync(tile_list + RLQ_PENDING, 0, (RL_HDR - RLQ_PENDING) * sizeof(uint32_t), s);
+          if (e != hipSuccess) return e;
+          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, 1);
+          if ((e = hipGetLastError()) != hipSuccess) return e;
+          k_relax<RX_SNW, true, true, true, true, 0, true><<<std::min<unsigned>(RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy)), 64 * RX_SNW, 0, s>>>(
+              img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
+              check_carry, pad, tile_list, 0, 1, 1, list_cap, 1);
+          if ((e = hipGetLastError()) != hipSuccess) return e;
+          k_relax_list_all<RX_STW, RX_STH><<<(unsigned)((std::max<size_t>((size_t)gx * gy, list_cap + 1) + 255) / 256), 256, 0, s>>>(h, w, gx, gy, pass + 1, tile_list, list_cap);
+          return hipGetLastError();
+        }
         if (split && pass == same_from)
-          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap);
+          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, 0);
         else if (split)
           k_relax_list<RX_STW, RX_STH><<<blocks, 256, 0, s>>>(h, w, gx, gy, gx, gy, 0, pass, prev, tile_list, 1, list_cap);
         else

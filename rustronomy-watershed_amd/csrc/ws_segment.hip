@@ -284,7 +284,7 @@ int run_sweep(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, ui
 }
 
 int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
-                 size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels) {
+                 size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels, uint32_t *out_labels_u32 = nullptr) {
   if (!c) return WS_ERR_BAD_ARG;
   size_t ph, pw;
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
@@ -331,6 +331,8 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
     HIP_TRY(c, widen_labels(c->stream, d_labels, d_out64, n));
     HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   }
+  if (out_labels_u32 && n)      // ws_segment_u32: the device's own 4-byte labels, half the bytes over PCIe
+    HIP_TRY(c, hipMemcpyAsync(out_labels_u32, d_labels, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   return stats_end(c);
 }
 
@@ -345,6 +347,13 @@ int ws_segment(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride,
   if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!out_labels) return fail(c, WS_ERR_BAD_ARG, "out_labels is null");
   return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, out_labels);
+}
+
+int ws_segment_u32(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                   size_t n_seeds, const ws_options *opt, uint32_t *out_labels) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!out_labels) return fail(c, WS_ERR_BAD_ARG, "out_labels is null");
+  return segment_host(c, img, h, w, stride, seeds_rc, n_seeds, opt, nullptr, nullptr, nullptr, out_labels);
 }
 
 int ws_segment_with_hook(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,

@@ -92,6 +92,8 @@ def test_transform_to_list_device_2048_lake_sizes_equal_oracle(pkg):
     want = {}
     ol.merge_arrival(img, seeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)) if l in levels else None)
     eng = _engine()
+    # the form of the lists that 4096^2 planes and larger take (records from the list of LIVE lakes), here at 457 k colours
+    assert pkg._ffi.lib().ws_ctx_set_live_list_min_colours(eng.ctx.handle, 1000) == 0
     d_img = torch.from_numpy(img).to(eng.device)
     d_seeds = torch.from_numpy(np.asarray(seeds, dtype=np.int64).astype(np.int32)).to(eng.device).reshape(-1, 2).contiguous()
     lakes, offsets, unc = eng.transform_to_list(d_img, d_seeds, merging=True)

@@ -253,6 +253,23 @@ def test_device_path_matches_host_path(pkg):
     assert (labels.cpu().numpy().view(np.uint32) == ol.segment_arrival(himg, hseeds)).all()
 
 
+def test_segment_u32_host_labels_equal_the_usize_plane(pkg):
+    # ws_segment_u32: the same transform with the labels as the device holds them (half the bytes over PCIe)
+    import ctypes
+    img = cases.field(300, 420, 6)
+    seeds = np.ascontiguousarray(np.asarray(ol.find_local_minima(img), dtype=np.uint64))
+    want = ol.segment(img, seeds)
+    for edge in (False, True):
+        ws = _seg(pkg, edge=edge)
+        c, opt = ws._ctx(), ws._opt
+        e = 2 if edge else 0
+        out = np.zeros((300 + e, 420 + e), dtype=np.uint32)
+        rc = pkg._ffi.lib().ws_segment_u32(c.handle, img.ctypes.data, 300, 420, 420, seeds.ctypes.data, len(seeds), ctypes.byref(opt), out.ctypes.data)
+        assert rc == 0, rc
+        assert (out == (ol.segment(img, seeds, edge=True) if edge else want)).all()
+        assert pkg._ffi.lib().ws_segment_u32(c.handle, img.ctypes.data, 300, 420, 420, seeds.ctypes.data, len(seeds), ctypes.byref(opt), None) == pkg._ffi.WS_ERR_BAD_ARG
+
+
 @pytest.mark.parametrize("size", [4096, 8192])
 def test_full_size_fixpoint_properties(pkg, size):
     # BASELINE.json headline size (8192^2) and the C4 slice size (4096^2): the oracle cannot run
