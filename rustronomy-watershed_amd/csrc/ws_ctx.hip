@@ -280,6 +280,13 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *c, size_t min_px) {
   return WS_OK;
 }
 
+int ws_ctx_set_persistent_pass(ws_ctx *c, int enabled) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c) return WS_ERR_BAD_ARG;
+  c->persistent_pass = enabled != 0;
+  return WS_OK;
+}
+
 int ws_ctx_set_live_list_min_colours(ws_ctx *c, size_t min_colours) {
   if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
   if (!c) return WS_ERR_BAD_ARG;

@@ -34,6 +34,7 @@
 #include "ws_common.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace wsk {
@@ -134,34 +135,37 @@ constexpr uint32_t ST_SELF = 0x80000000u;        // (word 0) the tile stopped at
 constexpr uint32_t ST_PASS = 0x3FFFFFFFu;
 constexpr uint32_t RX_CAND = 64;      // candidates a workgroup collects before it hands them in (k_relax, append_flush)
 // tile_list header: [0 .. 3] list lengths and [4 .. 7] entry tickets of pass & 3 (a launch clears the words of pass + 2)
-constexpr uint32_t RL_HDR = 16;
+constexpr uint32_t RL_HDR = 192;
 // ... and, for the persistent tile-queue pass (k_relax, PERSIST): [8] tiles queued or running, [9] "the queue has run dry" (1) or
 // "a worker ran out of its time budget" (2), [10] tile runs (diagnostics)
-constexpr uint32_t RLQ_PENDING = 8, RLQ_DONE = 9, RLQ_RUNS = 10;
+constexpr uint32_t RLQ_PHASE = 16;      // -DWS_TUNING: ticks of thread 0 per phase of a tile run, summed (load, rounds, epilogue, hand-in)
+// Every word that all workers hammer sits on a 128-byte line of its own: head, tail, pending and the end flag in ONE line
+// were ~100 atomics and polls per microsecond on one L2 channel, and an atomic round trip took 3 us (a tile run 49 us
+// instead of 15).
+constexpr uint32_t RLQ_HEAD = 32, RLQ_TAIL = 64, RLQ_PENDING = 96, RLQ_DONE = 128;
+constexpr uint32_t RLQ_RUNS = 10, RLQ_WAIT = 11, RLQ_LIFE = 12, RLQ_POLLS = 13;      // (11-13: all workers' waiting / life time in 10 ns ticks, polls)
 // A worker gives up -- and tells the others to -- when the launch has lasted this long (s_memrealtime ticks of 10 ns): no spin
 // of this kernel can outlive it, whatever goes wrong with the queue.  What is left undone is work for the passes that follow.
 constexpr unsigned long long RLQ_BUDGET_TICKS = 5000000ull;      // 50 ms; a smooth 8192^2 map needs 3
+// Rounds per tile run of the persistent pass.  The ordinary late passes stop a tile after three (a pass ends when its slowest
+// tile ends); without a pass barrier that reason is gone and a run's fixed costs (loads, stores, queue: ~10 us) are spread over
+// more rounds: 8192^2 smooth maps, correlation 16 px: 6.74 ms with three, 6.36 with six, 6.28 with twelve.
+constexpr uint32_t RLQ_ROUND_CAP = 6;
 
 // Stamp accesses of the persistent pass: tiles hand their border pixels to each other INSIDE a launch, across CUs and XCDs,
-// so every stamp is stored write-through and loaded past L1 at agent scope (global_store / global_load ... sc1), 8 bytes a
-// time (the widest agent-scope access HIP's atomics offer; MI355X_MICROARCH.md, inter-workgroup visibility).
-template <bool COH>
-__device__ __forceinline__ u32x4_t ld_stamps4(const uint32_t *p) {
-  if (!COH) return *reinterpret_cast<const u32x4_t *>(p);
-  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+// so every stamp is stored write-through and loaded past L1 at agent scope (global_store / global_load ... sc1;
+// MI355X_MICROARCH.md, inter-workgroup visibility).  Inline assembly, because HIP's agent-scope atomic loads are 8 bytes at
+// most and each is waited for on its own: 24 dependent round trips per lane and tile run (52 us per run against 12).  The
+// loads below are issued back to back and waited for ONCE (the wait's operands tie the loaded registers to it, so that no use
+// can be scheduled in front of it).
+__device__ __forceinline__ void coh_load4(u32x4_t &v, const uint32_t *p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
 }
-template <bool COH>
-__device__ __forceinline__ uint32_t ld_stamp(const uint32_t *p) {
-  if (!COH) return *p;
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void coh_load1(uint32_t &v, const uint32_t *p) {
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
 }
-template <bool COH>
-__device__ __forceinline__ void st_stamps4(uint32_t *p, u32x4_t v) {
-  if (!COH) { *reinterpret_cast<u32x4_t *>(p) = v; return; }
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p) + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void coh_store4(uint32_t *p, u32x4_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 template <int TW, int TH>
@@ -441,12 +445,24 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // PERSIST: the queue (see above)
   unsigned long long *q_ring = reinterpret_cast<unsigned long long *>(tile_list + RL_HDR);      // list_cap entries: (sequence + 1) << 32 | tile
   uint32_t *q_state = tile_list + RL_HDR + 2 * (size_t)list_cap;
-  uint32_t *q_head = tile_list + 4 + (pass & 3u), *q_tail = tile_list + (pass & 3u);
+  uint32_t *q_head = tile_list + RLQ_HEAD, *q_tail = tile_list + RLQ_TAIL;
   uint32_t *q_pending = tile_list + RLQ_PENDING, *q_done = tile_list + RLQ_DONE;
   __shared__ uint32_t s_qtile;
   unsigned long long q_t0 = 0;
+  uint32_t q_wait = 0, q_polls = 0;
+#ifdef WS_TUNING
+  uint32_t q_ph[4] = {0, 0, 0, 0};
+  unsigned long long q_tp = 0;
+#define WS_QPHASE(k) do { if (PERSIST && threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); q_ph[k] += (uint32_t)(n_ - q_tp); q_tp = n_; } } while (0)
+#define WS_QPHASE0 do { if (PERSIST && threadIdx.x == 0) q_tp = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WS_QPHASE(k) do {} while (0)
+#define WS_QPHASE0 do {} while (0)
+#endif
+  unsigned long long q_c0 = 0;
   if (PERSIST) {
     q_t0 = __builtin_amdgcn_s_memrealtime();
+    q_c0 = __builtin_amdgcn_s_memtime();
     // whatever this launch does, the passes after it look at every tile again: tell the host that they have to run
     if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
       pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT] = 1u;
@@ -519,23 +535,44 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     if (threadIdx.x == 0) {
       unsigned long long v = 0;
       if (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
         const uint32_t my = atomicAdd(q_head, 1u);
         unsigned long long *slot = q_ring + (my % list_cap);
-        for (;;) {
+        for (uint32_t spins = 0;; ++spins) {
           v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(v >> 32) == my + 1u) break;      // my entry (not one of the ring's previous lap)
           v = 0;
+          ++q_polls;
           if (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (__builtin_amdgcn_s_memrealtime() - q_t0 > RLQ_BUDGET_TICKS) { __hip_atomic_store(q_done, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-          __builtin_amdgcn_s_sleep(16);
+          // an idle worker must not cost the busy ones their memory bandwidth: the first polls come quickly (work usually
+          // arrives within a tile run), later ones every few microseconds
+          // Who is next in line polls quickly (the flood is often a chain of tile runs: this wait is on its critical path);
+          // who is far behind the tail sleeps longer -- an idle worker must not cost the busy ones their memory bandwidth.
+          const uint32_t behind = my - __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tickets drawn before mine and not yet filled
+          if (behind < 4u) __builtin_amdgcn_s_sleep(2);
+          else if (behind < 32u) __builtin_amdgcn_s_sleep(24);
+          else __builtin_amdgcn_s_sleep(127);
         }
+        q_wait += (uint32_t)(__builtin_amdgcn_s_memrealtime() - w0);
         if (v != 0) atomicExch(q_state + (uint32_t)v, 2u);      // queued -> running: whoever flags it from now on makes it run again
       }
       s_qtile = v != 0 ? (uint32_t)v + 1u : 0u;
     }
     __syncthreads();
     q_tile = s_qtile;
-    if (q_tile == 0) break;      // workgroup uniform: the queue has run dry (or the time budget is spent)
+    if (q_tile == 0) {           // workgroup uniform: the queue has run dry (or the time budget is spent)
+      if (threadIdx.x == 0) {
+        atomicAdd(tile_list + RLQ_WAIT, q_wait);
+        atomicAdd(tile_list + RLQ_LIFE, (uint32_t)(__builtin_amdgcn_s_memrealtime() - q_t0));
+        atomicAdd(tile_list + RLQ_POLLS, q_polls);
+#ifdef WS_TUNING
+        for (int k = 0; k < 4; ++k) atomicAdd(tile_list + RLQ_PHASE + k, q_ph[k]);
+        atomicAdd(tile_list + RLQ_PHASE + 4, (uint32_t)((__builtin_amdgcn_s_memtime() - q_c0) >> 8));      // shader cycles / 256
+#endif
+      }
+      break;
+    }
   }
   // re-derived per tile on purpose (the asm hides the value from loop-invariant hoisting): hoisted
   // per-lane addresses pushed the chunked variant over the 80-VGPR cap and into scratch
@@ -552,6 +589,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   const int seam_x = (tile_x * 32 + (lane >> 1) + 1) * SEAM_PX;      // SEAM 2: this lane pair's seam (outside the plane: no seam)
 
   WS_STAMP(0);
+  WS_QPHASE0;
   const int gx0 = SEAM == 2 ? (seam_x < W ? seam_x - SEAM_HALF + (lane & 1) * RX_P : W) : x0 + xl * RX_P, gyb = y0 + band * RX_P;
   if (tid == 0) { s_edges = 0; s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
   // List mode: entries are handed out by ticket, not in strides of the grid -- tile runs last 8 to 20 us, and with a fixed
@@ -607,11 +645,24 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       const int gyc = min(max(gyb + r, 0), H - 1);
-      kv[r] = ld_stamps4<PERSIST>(ksrc + (size_t)gyc * W + gxc0);
       iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
-      halo[r] = ld_stamp<PERSIST>(ksrc + (size_t)gyc * W + xh);
+      if (PERSIST && !(use_list & 1)) {      // (PERSIST: use_list carries the tuning build's A/B bits -- 1: plain stamp accesses, 2: slow polls)
+        coh_load4(kv[r], ksrc + (size_t)gyc * W + gxc0);
+        coh_load1(halo[r], ksrc + (size_t)gyc * W + xh);
+      } else {
+        kv[r] = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gyc * W + gxc0);
+        halo[r] = ksrc[(size_t)gyc * W + xh];
+      }
     }
-    halo_row = ld_stamps4<PERSIST>(ksrc + (size_t)gy_halo * W + gxc0);
+    if (PERSIST && !(use_list & 1)) {
+      coh_load4(halo_row, ksrc + (size_t)gy_halo * W + gxc0);
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(halo_row), "+v"(halo[0]), "+v"(halo[1]), "+v"(halo[2]), "+v"(halo[3])
+                   :
+                   : "memory");
+    } else {
+      halo_row = *reinterpret_cast<const u32x4_t *>(ksrc + (size_t)gy_halo * W + gxc0);
+    }
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       T[r][0] = kv[r].x; T[r][1] = kv[r].y; T[r][2] = kv[r].z; T[r][3] = kv[r].w;
@@ -730,6 +781,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   }
   __syncthreads();
   WS_STAMP(1);
+  WS_QPHASE(0);
 
   // ---- relaxation ---------------------------------------------------------------------------
   // One round = three free-running sweeps (down, right, up), a barrier that publishes the band
@@ -827,6 +879,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     any_lower = sum_after != s_sum[tid];
   }
   WS_STAMP(2);
+  WS_QPHASE(1);
   WS_ACC_STORE;
 #ifdef WS_DIAG_STAMPS
   if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = iters;
@@ -841,7 +894,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       const int gy = gyb + r;
       if (gy >= 0 && gy < H) {
         if (full_x) {
-          st_stamps4<PERSIST>(keys + (size_t)gy * W + gx0, u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]});
+          if (PERSIST && !(use_list & 1)) coh_store4(keys + (size_t)gy * W + gx0, u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]});
+          else *reinterpret_cast<u32x4_t *>(keys + (size_t)gy * W + gx0) = u32x4_t{T[r][0], T[r][1], T[r][2], T[r][3]};
         } else {
 #pragma unroll
           for (int c = 0; c < RX_P; ++c) if (gx0 + c >= 0 && gx0 + c < W) keys[(size_t)gy * W + gx0 + c] = T[r][c];
@@ -973,6 +1027,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     }
   }
   WS_STAMP(3);
+  WS_QPHASE(2);
   if (PERSIST) {
     __syncthreads();      // thread 0's candidates (s_cand, s_ncand: the append_next block above) are there
     if (tid < 64) {
@@ -990,7 +1045,10 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       const uint32_t total = nf + again;
       if (total) {
         uint32_t at = 0;
-        if (lane == 0) { atomicAdd(q_pending, total); at = atomicAdd(q_tail, total); }      // counted before anyone can take them
+        if (lane == 0) {      // counted before anyone can take them; my own run leaves the count in the same add
+          if (total != 1u) atomicAdd(q_pending, total - 1u);
+          at = atomicAdd(q_tail, total);
+        }
         at = (uint32_t)__shfl((int)at, 0, 64);
         if (fresh) {
           const uint32_t idx = at + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
@@ -1003,10 +1061,14 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       }
       if (lane == 0) {
         s_ncand = 0;
-        if (atomicSub(q_pending, 1u) == 1u) __hip_atomic_store(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nothing queued, nothing running
+        // nothing queued by me and my run is over: was mine the last tile queued or running?
+        if (total == 0u && atomicSub(q_pending, 1u) == 1u) __hip_atomic_store(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef WS_TUNING
         atomicAdd(tile_list + RLQ_RUNS, 1u);
+#endif
       }
     }
+    WS_QPHASE(3);
     continue;
   }
   // next tile of the chunk: every wave is past its last read of the shared arrays (barrier above)
@@ -1087,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int til
   if (todo == 0) return;
   uint32_t base = 0;
   if (lane == 0) {
-    base = atomicAdd(&tile_list[pass & 3u], (uint32_t)__popcll(todo));
+    base = atomicAdd(&tile_list[persist ? RLQ_TAIL : (pass & 3u)], (uint32_t)__popcll(todo));
     if (persist) atomicAdd(&tile_list[RLQ_PENDING], (uint32_t)__popcll(todo));
   }
   base = __shfl(base, 0, 64);
@@ -1160,7 +1222,7 @@ bool relax_uses_seam_repair(int h, int w, bool seed_bits, int slice_h, bool padd
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded,
-                      uint32_t *tile_list, size_t seam_min_px) {
+                      uint32_t *tile_list, size_t seam_min_px, bool persistent_pass) {
   const int th = RX_NW * RX_P;
   const int pad = padded ? 1 : 0;
   // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
@@ -1301,19 +1363,35 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         // The first same-grid pass as ONE persistent launch (k_relax, PERSIST): workgroups pull tiles from a queue and a tile
         // that changes something its neighbour must see queues that neighbour at once.  The pass after it runs every tile
         // from an all-tiles list, so the fixpoint is certified by the ordinary machinery whatever the queue did.
-        static const bool no_persist = tuning_env("WS_RELAX_NO_PERSIST") != nullptr;      // A/B knob, tools/ only
-        const bool persist = !no_persist && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
+        // Opt-in (ws_ctx_set_persistent_pass): 8192^2 smooth maps, correlation length 4 / 16 / 64 / 256 px: 3.07 / 6.05 / 7.03 / 3.65 ms
+        // with the passes, 3.01 / 6.36 / 6.36 / 4.05 ms with the queue (profiles/r3_v1_persistent_ab.txt) -- a tile run costs
+        // 13-17 us either way (4 us of loads past L2, 4-8 of scan rounds, 3 of write-through stores, 2 of queue atomics), the
+        // queue saves the launch gaps and the tails of the passes and pays for them with a sixth more tile runs (no pass
+        // barrier: a tile runs on the first flag instead of on all flags of a pass) and with slower hops along a thin front.
+        static const bool force_persist = tuning_env("WS_RELAX_PERSIST") != nullptr;      // A/B knob, tools/ only
+        const bool persist = (persistent_pass || force_persist) && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
                              ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap;
         if (persist) {
           hipError_t e = hipMemsetAsync(tile_list + RL_HDR, 0, 2 * (size_t)list_cap * sizeof(uint32_t), s);      // the ring: no entry yet
-          if (e == hipSuccess) e = hipMemsetAsync(tile_list + RLQ_PENDING, 0, (RL_HDR - RLQ_PENDING) * sizeof(uint32_t), s);
+          if (e == hipSuccess) e = hipMemsetAsync(tile_list + 8, 0, (RL_HDR - 8) * sizeof(uint32_t), s);      // counters (and diagnostics)
           if (e != hipSuccess) return e;
           k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
           k_relax<RX_SNW, true, true, true, true, 0, true><<<std::min<unsigned>(RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy)), 64 * RX_SNW, 0, s>>>(
-              img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, max_iters, nullptr, 0, sh,
-              check_carry, pad, tile_list, 0, 1, 1, list_cap, 1);
+              img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf,
+              tuning_env("WS_RELAX_PERSIST_CAP") ? (uint32_t)atoi(tuning_env("WS_RELAX_PERSIST_CAP")) : RLQ_ROUND_CAP, nullptr, 0, sh,
+              check_carry, pad, tile_list, tuning_env("WS_RELAX_PERSIST_MODE") ? atoi(tuning_env("WS_RELAX_PERSIST_MODE")) : 0, 1, 1, list_cap, 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
+          if (tuning_env("WS_RELAX_PERSIST_DIAG")) {      // tools/ only: what the workers did
+            uint32_t hd[RL_HDR];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hd, tile_list, sizeof hd, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ws] persistent pass %u: pushed %u popped %u pending %u done %u runs %u | workers wait %.1f us, life %.1f us (sums / 512), polls %u\n", pass,
+                    hd[RLQ_TAIL], hd[RLQ_HEAD], hd[RLQ_PENDING], hd[RLQ_DONE], hd[RLQ_RUNS], hd[RLQ_WAIT] / 100.0 / 512.0, hd[RLQ_LIFE] / 100.0 / 512.0, hd[RLQ_POLLS]);
+            const double runs = hd[RLQ_RUNS] ? hd[RLQ_RUNS] : 1;
+            fprintf(stderr, "[ws]   per tile run (us): load %.2f rounds %.2f epilogue %.2f hand-in %.2f; shader clock %.0f MHz\n", hd[RLQ_PHASE] / 100.0 / runs, hd[RLQ_PHASE + 1] / 100.0 / runs,
+                    hd[RLQ_PHASE + 2] / 100.0 / runs, hd[RLQ_PHASE + 3] / 100.0 / runs, hd[RLQ_LIFE] ? 256.0 * hd[RLQ_PHASE + 4] / hd[RLQ_LIFE] * 100.0 : 0.0);
+          }
           k_relax_list_all<RX_STW, RX_STH><<<(unsigned)((std::max<size_t>((size_t)gx * gy, list_cap + 1) + 255) / 256), 256, 0, s>>>(h, w, gx, gy, pass + 1, tile_list, list_cap);
           return hipGetLastError();
         }

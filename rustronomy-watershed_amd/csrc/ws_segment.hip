@@ -75,7 +75,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     hipError_t e = seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
                                relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
-      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px);
+      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px, c->persistent_pass);
     const uint32_t last = GRAPH_PASSES - 1;
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
@@ -156,7 +156,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto launch_pass = [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list, c->seam_min_px);
+                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list, c->seam_min_px, c->persistent_pass);
   };
   if (graph_mode != 0) {
     // the graph ran seed tables, passes 0 .. GRAPH_PASSES - 1, the gated resolve and the read-backs

@@ -341,6 +341,35 @@ def test_segment_large_smooth_fields_long_range(pkg, shape, octaves, few_seeds):
     assert st["relax_passes"] >= 8           # the scan-capable kernel variant ran (passes >= 4)
 
 
+@pytest.mark.parametrize("shape,octaves,few_seeds", [((1100, 1600), 6, False), ((900, 2048), 7, True), ((1500, 640), 7, True), ((2100, 300), 5, False)])
+def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, few_seeds):
+    # ws_ctx_set_persistent_pass: the first same-grid pass of a long-range flood as ONE launch with a device-side tile queue
+    # (k_relax, PERSIST).  Opt-in; the labels must be the oracle's whatever order the queue runs the tiles in.
+    img = cases.smooth_field(shape[0], shape[1], 11 + octaves, octaves=octaves)
+    seeds = ol.find_local_minima(img)
+    if few_seeds:
+        seeds = seeds[::max(len(seeds) // 3, 1)]
+    ws = _seg(pkg)
+    c = ws._ctx()
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 1) == 0
+    got = ws.transform(img, seeds)
+    st = c.stats()
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
+    assert st["relax_passes"] >= 9           # pass 7 was the queue, pass 8 looked at every tile again
+    assert (got == ol.segment_arrival(img, seeds)).all()
+    corridor = np.full((600, 1400), 255, dtype=np.uint8)      # one long winding corridor: a chain of tile runs, nothing in parallel
+    corridor[5:595:10, 3:-3] = 7
+    corridor[5:595:20, -6:-3] = 7
+    for r in range(5, 585, 10):
+        x = slice(-6, -3) if (r // 10) % 2 == 0 else slice(3, 6)
+        corridor[r:r + 11, x] = 7
+    cs = np.array([[5, 4]], dtype=np.uint64)
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 1) == 0
+    got = ws.transform(corridor, cs)
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
+    assert (got == ol.segment_arrival(corridor, cs)).all()
+
+
 def test_segment_batch_of_independent_slices(pkg):
     # config C4 in miniature: a cube of slices, one call; equal to slice-by-slice calls and to the oracle
     import importlib
