@@ -852,13 +852,19 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
     const size_t hg = (size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1);
     const uint32_t hv = keys[hg];
     const bool hok = hy >= 0 && hy < H && hx >= 0 && hx < W;
+    // (workgroup uniform: a tile that lies wholly inside the plane has nothing to mask -- this kernel is bound by vector issue)
+    if (!(x0 + TS <= W && y0 + TS <= H)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (!(gy0 + r < H && gx0 + c < W)) { K[r][c] = KEY_INF; Lb[r][c] = 0u; }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (!(gy0 + r < H && gx0 + c < W)) { K[r][c] = KEY_INF; Lb[r][c] = 0u; }
+      for (int c = 0; c < 4; ++c)
         if (TABLES && K[r][c] == 0u) seedbits |= 1u << (r * 4 + c);      // only a seed (stamp 0) has a colour of its own
-      }
       *reinterpret_cast<u32x4_r *>(&sB[(ly0 + r) * RL_P + lx0]) = u32x4_r{K[r][0], K[r][1], K[r][2], K[r][3]};
     }
     sB[(hy - (y0 - 1)) * RL_P + (hx - (x0 - 1)) + (RL_X0 - 1)] = hok ? hv : KEY_INF;
@@ -896,8 +902,11 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
       for (int c = 0; c < 4; ++c) {
         const uint32_t cell = (uint32_t)((ly0 + r) * RL_P + lx0 + c);
         const uint32_t k = K[r][c];
-        // flooded pixels are interior pixels (lib.rs:220-222) with a finite, non-seed stamp
-        const uint32_t flood = (uint32_t)(k - 1u < KEY_INF - 1u) & row_int[r] & col_int[c];
+        // flooded pixels are interior pixels (lib.rs:220-222) with a finite, non-seed stamp.  The relaxation never lowers the
+        // stamp of a border pixel of the image (or of a slice of a stack: its base is KEY_INF), so such a pixel is a seed or
+        // never coloured and the stamp alone says "not flooded"; only a row block's halo rows hold finite stamps on a border
+        // row (a neighbour rank's): BLOCK keeps the masks.
+        const uint32_t flood = BLOCK ? (uint32_t)(k - 1u < KEY_INF - 1u) & row_int[r] & col_int[c] : (uint32_t)(k - 1u < KEY_INF - 1u);
         // a finite stamp of a flooded pixel with ring 0: a carry out of the 24-bit ring field (the relaxation of a whole
         // transform leaves this test to the one kernel that reads the finished plane)
         // (smallest, over the flooded pixels, of the ring field moved to the top of the word: 0 = a carry; two ops per pixel)
@@ -1018,12 +1027,18 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[r][c] = sB[P[r][c] & (RL_HALO - 1u)];      // 16 independent reads, one wait
+  const bool whole = x0 + TS <= W && y0 + TS <= H;      // workgroup uniform
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gy = gy0 + r;
+    if (whole) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      refmask |= ((uint32_t)((out[r][c] & REF_BIT) != 0u) & (uint32_t)(gy < H) & (uint32_t)(gx0 + c < W)) << (r * 4 + c);
+      for (int c = 0; c < 4; ++c) refmask |= (out[r][c] >> 31) << (r * 4 + c);      // REF_BIT is the top bit
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        refmask |= ((uint32_t)((out[r][c] & REF_BIT) != 0u) & (uint32_t)(gy < H) & (uint32_t)(gx0 + c < W)) << (r * 4 + c);
+    }
     if (gy < H) {
       if (vec) {
         if (gx0 < W) *reinterpret_cast<u32x4_r *>(labels + (size_t)gy * W + gx0) = u32x4_r{out[r][0], out[r][1], out[r][2], out[r][3]};

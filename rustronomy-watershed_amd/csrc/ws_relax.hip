@@ -96,6 +96,32 @@ __device__ __forceinline__ uint32_t plane_or_bit(const uint32_t *src, size_t p, 
 
 typedef uint32_t patch_t[RX_P][RX_P];
 
+// The image bytes of a patch (one dword per row) -> the pixels' bases: (level << 24) | 1, or KEY_INF for a level that never
+// opens.  With the default maximum level, 254 (lib.rs:942), only byte 255 never opens, and (255 << 24) | 1 lies ABOVE every
+// stamp: the `b = min(b, t)` that follows every load pins such a pixel at its stamp by itself -- no compare, no select, and
+// the byte comes into place with one shift and one and-or (7 cycles per pixel instead of 16.5: these kernels are bound by
+// vector issue, profiles/r3_v0_issue_counters.json).  Called AFTER the loop that loads the rows, with its one (kernel
+// uniform) branch outside the row loop: a branch between two rows' loads makes every row a memory round trip of its own
+// (pass 0: 168 -> 189 us, measured).
+__device__ __forceinline__ void patch_bases(const uint32_t (&iv)[RX_P], patch_t &B, uint32_t max_level) {
+  if (max_level == 254u) {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r) {
+      B[r][0] = (iv[r] << 24) | 1u;
+      B[r][1] = ((iv[r] << 16) & 0xFF000000u) | 1u;
+      B[r][2] = ((iv[r] << 8) & 0xFF000000u) | 1u;
+      B[r][3] = (iv[r] & 0xFF000000u) | 1u;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RX_P; ++r)
+#pragma unroll
+      for (int c = 0; c < RX_P; ++c) {
+        const uint32_t v = (iv[r] >> (8 * c)) & 0xFFu;
+        B[r][c] = v <= max_level ? ((v << 24) | 1u) : KEY_INF;
+      }
+  }
+}
 
 // A sweep walks the patch rows (or columns) in its direction and, inside a row, the pixels left to right
 // (top to bottom), every pixel seeing its neighbours as they are NOW -- Gauss-Seidel all the way.  (Any
@@ -459,10 +485,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #define WS_QPHASE(k) do {} while (0)
 #define WS_QPHASE0 do {} while (0)
 #endif
-  unsigned long long q_c0 = 0;
+#ifdef WS_TUNING
+  const unsigned long long q_c0 = PERSIST ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
   if (PERSIST) {
     q_t0 = __builtin_amdgcn_s_memrealtime();
-    q_c0 = __builtin_amdgcn_s_memtime();
     // whatever this launch does, the passes after it look at every tile again: tell the host that they have to run
     if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
       pf.edge_changed[(pass % COUNTER_RING) * FLAG_SLOT] = 1u;
@@ -538,7 +565,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
         const uint32_t my = atomicAdd(q_head, 1u);
         unsigned long long *slot = q_ring + (my % list_cap);
-        for (uint32_t spins = 0;; ++spins) {
+        for (;;) {
           v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(v >> 32) == my + 1u) break;      // my entry (not one of the ring's previous lap)
           v = 0;
@@ -605,7 +632,11 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   // patch is either wholly inside or wholly outside)
   // (pad: the image is the caller's unpadded one, read through padded_img_index -- byte loads)
   const bool fast = !pad && W >= RX_P && ((SEAM != 2 && x0 >= 0 && x0 + TW <= W) || (W & 3) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0;
+                    ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && img_stride <= 0xFFFFFFFFull;
+  // Index arithmetic of the fast paths in 32 bits where the plane allows it: the first form of these loads spent 22 vector
+  // instructions per patch row on addresses, five of them 64-bit multiplies (v_mad_i64_i32, v_mul_lo_u32: quarter rate).
+  const uint32_t stride32 = (uint32_t)img_stride;
+  const bool dims24 = (uint32_t)W < (1u << 24) && (uint32_t)H < (1u << 24);      // kernel uniform: row * W as v_mul_u32_u24
   const int gxc0 = min(max(gx0, 0), max(W - RX_P, 0));
   // tile halo columns: the left half of a row's lanes fetch the column left of the tile, the right half the one right
   // of it; only the first / last lane of a row ever use the value (as the DPP `old` operand)
@@ -627,16 +658,17 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     uint32_t iv[RX_P];
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
-      const int gyc = min(max(gyb + r, 0), H - 1);
-      const size_t p = (size_t)gyc * W + gxc0, ph_ = (size_t)gyc * W + xh;
+      const uint32_t gyc = (uint32_t)min(max(gyb + r, 0), H - 1);
+      // (a bit plane exists only for planes of fewer than 2^31 pixels: pixel indices fit 32 bits)
+      const uint32_t ro = dims24 ? __umul24(gyc, (uint32_t)W) : gyc * (uint32_t)W;
+      const uint32_t p = ro + (uint32_t)gxc0, ph_ = ro + (uint32_t)xh;
       const uint32_t nib = ksrc[p >> 5] >> (p & 31u);
-      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
+      iv[r] = *reinterpret_cast<const uint32_t *>(img + ((unsigned long long)gyc * stride32 + (uint32_t)gxc0));
       halo[r] = (ksrc[ph_ >> 5] >> (ph_ & 31u)) & 1u;
       T[r][0] = nib & 1u; T[r][1] = nib & 2u; T[r][2] = nib & 4u; T[r][3] = nib & 8u;
-#pragma unroll
-      for (int c = 0; c < RX_P; ++c) B[r][c] = (iv[r] >> (8 * c)) & 0xFFu;
     }
-    const size_t p = (size_t)gy_halo * W + gxc0;
+    patch_bases(iv, B, max_level);
+    const uint32_t p = (dims24 ? __umul24((uint32_t)gy_halo, (uint32_t)W) : (uint32_t)gy_halo * (uint32_t)W) + (uint32_t)gxc0;
     const uint32_t nib = ksrc[p >> 5] >> (p & 31u);
     halo_row = u32x4_t{nib & 1u, nib & 2u, nib & 4u, nib & 8u};
   } else if (fast) {
@@ -645,7 +677,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       const int gyc = min(max(gyb + r, 0), H - 1);
-      iv[r] = *reinterpret_cast<const uint32_t *>(img + (size_t)gyc * img_stride + gxc0);
+      iv[r] = *reinterpret_cast<const uint32_t *>(img + ((unsigned long long)(uint32_t)gyc * stride32 + (uint32_t)gxc0));
       if (PERSIST && !(use_list & 1)) {      // (PERSIST: use_list carries the tuning build's A/B bits -- 1: plain stamp accesses, 2: slow polls)
         coh_load4(kv[r], ksrc + (size_t)gyc * W + gxc0);
         coh_load1(halo[r], ksrc + (size_t)gyc * W + xh);
@@ -666,9 +698,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
       T[r][0] = kv[r].x; T[r][1] = kv[r].y; T[r][2] = kv[r].z; T[r][3] = kv[r].w;
-#pragma unroll
-      for (int c = 0; c < RX_P; ++c) B[r][c] = (iv[r] >> (8 * c)) & 0xFFu;
     }
+    patch_bases(iv, B, max_level);
   } else {
 #pragma unroll
     for (int r = 0; r < RX_P; ++r) {
@@ -677,7 +708,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       for (int c = 0; c < RX_P; ++c) {
         const int gxc = min(max(gx0 + c, 0), W - 1);
         T[r][c] = plane_or_bit(ksrc, (size_t)gyc * W + gxc, seed_bits);
-        B[r][c] = img[pad ? padded_img_index(gyc, gxc, W, SH, img_stride) : (size_t)gyc * img_stride + gxc];
+        const uint32_t v = img[pad ? padded_img_index(gyc, gxc, W, SH, img_stride) : (size_t)gyc * img_stride + gxc];
+        B[r][c] = v <= max_level ? ((v << 24) | 1u) : KEY_INF;
       }
       halo[r] = plane_or_bit(ksrc, (size_t)gyc * W + xh, seed_bits);
     }
@@ -696,12 +728,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     halo_row.x = halo_row.x ? 0u : KEY_INF; halo_row.y = halo_row.y ? 0u : KEY_INF;
     halo_row.z = halo_row.z ? 0u : KEY_INF; halo_row.w = halo_row.w ? 0u : KEY_INF;
   }
-  // bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224); everything else, and every
-  // seed (stamp 0 < base), is pinned at its current stamp: b = t
-#pragma unroll
-  for (int r = 0; r < RX_P; ++r)
-#pragma unroll
-    for (int c = 0; c < RX_P; ++c) B[r][c] = B[r][c] <= max_level ? ((B[r][c] << 24) | 1u) : KEY_INF;
+  // (bases: only interior pixels with img <= max level can ever be flooded (lib.rs:220-224); everything else, and every
+  // seed (stamp 0 < base), is pinned at its current stamp: b = t -- patch_bases above, the border masks and the min below)
   // Workgroup uniform: the tile and its halo ring lie strictly inside the image (and the image is not a stack of
   // slices) -- every pixel is in the plane and interior, none of the masks below can bite.  These kernels are VALU-bound
   // (VALUBusy 76-84 %, profiles/), and the masks were ~8 ops per pixel of a tile run's ~60.
