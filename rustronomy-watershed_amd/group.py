@@ -109,6 +109,7 @@ class Group:
             keep += [img, loc, lab]
             spans.append((r0, r1, lo, lab))
             blocks[i] = _ffi.TileBlock(img.data_ptr(), loc.data_ptr() if i1 > i0 else None, None, i1 - i0, i0 + 1, 0, lab.data_ptr())
+        torch.cuda.synchronize()      # the blocks were cut on torch's streams; the group's contexts run on streams of their own
         return blocks, spans, keep
 
     def segment_tiled_device(self, field_rows, width, n_seeds_total, blocks, max_level=254, merging=False):
