@@ -492,7 +492,6 @@ __device__ __forceinline__ void emit_alive_body(const uint2 *__restrict__ sd, si
                                                 uint32_t *alive_out, uint64_t *lakes, size_t cap, u64c *level_counts, uint32_t L,
                                                 unsigned bid, unsigned nblocks) {
   __shared__ u64c s_base, s_first;
-  __shared__ uint32_t s_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) {      // records of the earlier levels: their counters are final (earlier launches)
     u64c before = 0;

@@ -3,6 +3,8 @@
 Bar: bit-exact labels (integer work).  Sizes the sweep oracle finishes in seconds are compared
 directly; larger fields against the arrival-form oracle (itself proven equal to the sweep form
 in test_oracle_golden.py); BASELINE.json's full sizes through size-independent properties."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -156,6 +158,13 @@ def test_no_seeds_and_empty_images(pkg):
     for shape in ((0, 0), (0, 5), (5, 0), (1, 1), (2, 2)):
         out = _seg(pkg).transform(np.zeros(shape, np.uint8), [])
         assert out.shape == shape
+    # edge correction of an EMPTY image with a long side: the plane is two border rows (columns) of that length, and the
+    # kernels read a clamped address of the stand-in block for every one of its pixels (the block is sized by the long side)
+    for shape in ((0, 5000), (5000, 0), (0, 100003)):
+        out = _seg(pkg, edge=True).transform(np.zeros(shape, np.uint8), [])
+        assert out.shape == (shape[0] + 2, shape[1] + 2) and out.sum() == 0
+        out = _seg(pkg, edge=True).transform(np.zeros(shape, np.uint8), [(0, 1), (1, 0)] if shape[1] else [(0, 0)])
+        assert out.shape == (shape[0] + 2, shape[1] + 2) and int((out != 0).sum()) == (2 if shape[1] else 1)      # seeds keep their colour, nothing floods
 
 
 # ---- hooks / history (lib.rs:1796-1804, 1824-1835) ----------------------------------------
@@ -802,6 +811,24 @@ def _pipelined_begin_end(pkg, dev, torch, mode):
         engines[0].segment(img, seeds, out=outs[0])
     with pytest.raises(pkg.WatershedError):
         engines[0].find_local_minima(img)         # any other work on a context that holds a transform
+    # ... the row-block entry points and the context setters included: they rewrite stamps, flags, tables and work lists that
+    # the transform in flight (and its _end half) still uses
+    L, hnd, BAD = pkg._ffi.lib(), engines[0].ctx.handle, pkg._ffi.WS_ERR_BAD_ARG
+    hh, ww = int(img.shape[0]), int(img.shape[1])
+    keys = torch.empty((hh, ww), dtype=torch.int32, device=img.device)
+    chg = ctypes.c_int(0)
+    assert L.ws_block_begin(hnd, img.data_ptr(), hh, ww, ww, 254, seeds.data_ptr(), int(seeds.shape[0]), 1, keys.data_ptr()) == BAD
+    assert L.ws_block_relax_halo(hnd, img.data_ptr(), hh, ww, ww, 254, 1, 0, keys.data_ptr()) == BAD
+    assert L.ws_block_resolve_local(hnd, keys.data_ptr(), outs[1].data_ptr(), hh, ww, 1, 0) == BAD
+    assert L.ws_block_init(hnd, hh, ww, seeds.data_ptr(), seeds.data_ptr(), 0, keys.data_ptr(), outs[1].data_ptr()) == BAD
+    assert L.ws_block_relax(hnd, img.data_ptr(), hh, ww, ww, 254, keys.data_ptr(), ctypes.byref(chg)) == BAD
+    assert L.ws_block_resolve(hnd, keys.data_ptr(), outs[1].data_ptr(), hh, ww, ctypes.byref(chg)) == BAD
+    assert L.ws_block_merge_import(hnd, keys.data_ptr(), 0, keys.data_ptr()) == BAD
+    assert L.ws_ctx_set_profiling(hnd, 1) == BAD
+    assert L.ws_ctx_set_seam_repair_min_pixels(hnd, 4096) == BAD
+    assert L.ws_ctx_set_batch_pixel_limit(hnd, 4096) == BAD
+    assert L.ws_ctx_set_persistent_pass(hnd, 1) == BAD
+    assert L.ws_ctx_set_live_list_min_colours(hnd, 1) == BAD
     engines[0].segment_end()
     assert (engines[0].segment(img, seeds, out=outs[0]).cpu().numpy().view(np.uint32) == want).all()
     # the merging transform in two halves: the replayed graph and the unions queued behind it are left in flight; a flood

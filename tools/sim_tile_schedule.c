@@ -230,6 +230,68 @@ int main(int argc, char **argv) {
   long passes = 0, runs = 0, waves = 0;
   const int verbose = getenv("SIM_VERBOSE") != NULL;
   g_matters = getenv("SIM_MATTERS") ? atoi(getenv("SIM_MATTERS")) : 0;
+  if (getenv("SIM_QUEUE")) {
+    /* SIM_QUEUE=fifo|prio: no passes at all -- SIM_WORKERS (512) workers take tiles off a queue; a finished run queues the
+     * neighbours whose border it changed (a neighbour that is running is marked and queues itself when it ends).  prio: the
+     * worker takes the queued tile with the smallest pending stamp >> SIM_PRIO_SHIFT (24: its level), oldest first among
+     * equals.  A run costs SIM_COST="fixed,per_round" microseconds (8,3); its result is applied when it starts (a little
+     * optimistic: the kernel publishes at the end), its flags are delivered when it ends. */
+    const int prio = strcmp(getenv("SIM_QUEUE"), "prio") == 0;
+    const int W = getenv("SIM_WORKERS") ? atoi(getenv("SIM_WORKERS")) : 512;
+    const int shift = getenv("SIM_PRIO_SHIFT") ? atoi(getenv("SIM_PRIO_SHIFT")) : 24;
+    double c_fixed = 8.0, c_round = 3.0;
+    if (getenv("SIM_COST")) sscanf(getenv("SIM_COST"), "%lf,%lf", &c_fixed, &c_round);
+    const size_t T = (size_t)tx * ty;
+    uint8_t *state = calloc(T, 1);          /* 0 idle, 1 queued, 2 running, 3 running and flagged again */
+    uint64_t *seq = calloc(T, 8);
+    uint64_t next_seq = 1;
+    struct Run { double end; size_t t; int r; uint32_t side[5]; } *run = calloc((size_t)W, sizeof *run);
+    int busy = 0;
+    for (size_t t = 0; t < T; ++t) { state[t] = 1; seq[t] = next_seq++; pending[t] = 0; }
+    free(snap); snap = key;      /* a run reads the plane as it is when it starts */
+    double now = 0.0, work = 0.0;
+    long queued = (long)T;
+    for (;;) {
+      while (busy < W && queued > 0) {
+        size_t best = T;
+        for (size_t t = 0; t < T; ++t) {
+          if (state[t] != 1) continue;
+          if (best == T) { best = t; continue; }
+          const uint32_t a = prio ? pending[t] >> shift : 0, b = prio ? pending[best] >> shift : 0;
+          if (a < b || (a == b && seq[t] < seq[best])) best = t;
+        }
+        const long r0 = g_rounds;
+        const int i = (int)(best % tx), j = (int)(best / tx);
+        state[best] = 2; pending[best] = 0xFFFFFFFFu; --queued;
+        const int r = run_tile(i * tw, j * th, tw, th, cap, recipe);
+        const double c = c_fixed + c_round * (double)(g_rounds - r0);
+        work += c; ++runs;
+        run[busy].end = now + c; run[busy].t = best; run[busy].r = r;
+        memcpy(run[busy].side, g_side_min, sizeof g_side_min);
+        ++busy;
+      }
+      if (!busy) break;
+      int k = 0;
+      for (int q = 1; q < busy; ++q) if (run[q].end < run[k].end) k = q;
+      const struct Run e = run[k];
+      run[k] = run[--busy];
+      now = e.end;
+      const size_t t = e.t;
+      const int i = (int)(t % tx), j = (int)(t / tx);
+#define NOTE(tt, v) do { if ((v) < pending[tt]) pending[tt] = (v); if (state[tt] == 0) { state[tt] = 1; seq[tt] = next_seq++; ++queued; } else if (state[tt] == 2) state[tt] = 3; } while (0)
+      if ((e.r & 1) && j > 0) NOTE(t - tx, e.side[0]);
+      if ((e.r & 2) && j + 1 < ty) NOTE(t + tx, e.side[1]);
+      if ((e.r & 4) && i > 0) NOTE(t - 1, e.side[2]);
+      if ((e.r & 8) && i + 1 < tx) NOTE(t + 1, e.side[3]);
+      if (state[t] == 3 || (e.r & 32)) { if ((e.r & 32) && e.side[4] < pending[t]) pending[t] = e.side[4]; state[t] = 1; seq[t] = next_seq++; ++queued; }
+      else state[t] = 0;
+    }
+    uint64_t sum = 0;
+    for (size_t p = 0; p < n; ++p) sum += key[p] * (uint64_t)(p % 1000003 + 1);
+    printf("queue %-4s workers %d tile %d x %d cap %d %s: tile runs %ld (%.1f per tile) rounds %ld  makespan %.0f us  work %.0f us (%.0f %% of the workers' time)  checksum %llx\n",
+           prio ? "prio" : "fifo", W, tw, th, cap, recipe, runs, (double)runs / (double)T, g_rounds, now, work, 100.0 * work / (now * W), (unsigned long long)sum);
+    return 0;
+  }
   for (;;) {
     long ran = 0, waiting = 0;
     const long r0 = g_rounds;
