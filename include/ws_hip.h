@@ -163,12 +163,16 @@ int ws_ctx_set_batch_pixel_limit(ws_ctx *ctx, size_t max_px);
  * default, 2^24: smaller planes are bound by launch gaps and gain nothing.  (Tests lower it to cover the path on small planes.) */
 int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
 /* Long-range floods (smooth maps: a flood crosses thousands of pixels and the relaxation needs a hundred passes and more): with
- * this on, the first pass of the late, same-grid regime is ONE persistent launch in which workgroups pull 128 x 64 tiles from a
- * device-side queue and a tile that changes something its neighbour must see queues that neighbour at once (stamps handed
- * over write-through / past L1 at agent scope); the pass after it looks at every tile again, so the labels are the same either
- * way.  Off by default: measured on 8192^2 smooth maps it is 10 % faster at a correlation length of 64 px and 5-11 % slower at
- * 16 and 256 px.  Transforms that converge in a few passes (random fields) never reach that pass. */
-int ws_ctx_set_persistent_pass(ws_ctx *ctx, int enabled);
+ * mode 1 or 2 the first pass of the late, same-grid regime is ONE persistent launch in which workgroups pull 128 x 64 tiles from
+ * a device-side queue and a tile that changes something its neighbour must see queues that neighbour at once (stamps handed
+ * over write-through / past L1 at agent scope); the pass after it looks at every tile again, so the labels are the same in
+ * every mode.  1: first come, first served (a ring).  2: in flood order -- 31 buckets by the level of the smallest stamp that
+ * waits at a tile's borders, the lowest non-empty bucket first, and a run that announces a tile of its own bucket takes it
+ * itself.  0 (the default): the ordinary passes.  Measured on 8192^2 smooth maps of correlation length 4 / 16 / 64 / 256 px:
+ * 3.0 / 6.0 / 6.9 / 3.6 ms with the passes, 3.0 / 6.4 / 6.4 / 4.1 with mode 1, 3.8 / 7.2 / 5.0 / 4.0 with mode 2 (DESIGN.md
+ * section 10, profiles/r3_v1_persistent_ab.txt): mode 2 pays where few floods cross the whole plane.  Transforms that converge in a
+ * few passes (random fields) never reach that pass.  WS_ERR_BAD_ARG for any other mode. */
+int ws_ctx_set_persistent_pass(ws_ctx *ctx, int mode);
 /* The merging transform_to_list of a seed list with at least this many entries writes every level's lake records from the
  * list of the lakes alive at the level before, instead of looking at every colour at every level (same records, the order
  * inside a level differs).  0 restores the default, 2^20: fewer colours are bound by launch latency and gain nothing.

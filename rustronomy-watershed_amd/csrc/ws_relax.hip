@@ -177,6 +177,22 @@ constexpr unsigned long long RLQ_BUDGET_TICKS = 5000000ull;      // 50 ms; a smo
 // tile ends); without a pass barrier that reason is gone and a run's fixed costs (loads, stores, queue: ~10 us) are spread over
 // more rounds: 8192^2 smooth maps, correlation 16 px: 6.74 ms with three, 6.36 with six, 6.28 with twelve.
 constexpr uint32_t RLQ_ROUND_CAP = 6;
+// PERSIST == 2, the queue in flood order: a worker takes a tile from the LOWEST non-empty of PQ_B buckets; a tile's bucket is the
+// level (>> pq_shift) of the smallest stamp waiting at its borders.  tools/sim_tile_schedule.c (SIM_QUEUE=prio): on an 8192^2
+// map of correlation length 64 px first-come order needs 152 k tile runs, this order 87 k with 32 buckets (86 k with 256):
+// a tile that waits until the flood below it has passed runs once on final borders instead of once per arrival.
+//   state   one word per tile: bit 31 running; bits 0 .. 30 "a stamp of bucket b waits" (idle: 0).  A tile that is not running and
+//           has bits set is queued: its bit is set in the bitmap of its lowest bucket;
+//   bucket  a bitmap over the tiles (idempotent: no ring, no overflow, no lap) and a count of its set bits; the 31 counts and a
+//           copy of the end flag share ONE 128-byte line, so that a worker's look at all of them is one memory request (a line
+//           per count: 32 requests per look, and the idle workers' looks alone slowed every tile load from 4 us to 21).
+//           A stale bit (its tile runs, or has run from a lower bucket) costs a failed claim or one idle run.
+constexpr int PQ_B = 31;
+constexpr uint32_t PQ_RUNNING = 0x80000000u;
+constexpr uint32_t PQ_HDR = 32;      // the counts' line: [b] set bits of bucket b, [31] the end flag again
+__host__ __device__ inline size_t pq_base(uint32_t list_cap) { return (RL_HDR + 3 * (size_t)list_cap + 64 + 31) & ~(size_t)31; }
+__host__ __device__ inline uint32_t pq_words_per_bucket(uint32_t tiles) { return ((tiles + 31u) / 32u + 255u) & ~255u; }      // whole 1 KiB chunks: one load of a wave
+__host__ __device__ inline uint32_t pq_shift_of(uint32_t max_level) { return 24u + (max_level >= 124u ? 3u : max_level >= 62u ? 2u : max_level >= 31u ? 1u : 0u); }
 
 // Stamp accesses of the persistent pass: tiles hand their border pixels to each other INSIDE a launch, across CUs and XCDs,
 // so every stamp is stored write-through and loaded past L1 at agent scope (global_store / global_load ... sc1;
@@ -402,7 +418,7 @@ __device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uin
 // Exactness does not rest on any of this: stamps only ever fall, by relaxation steps from upper bounds (a stale read is an
 // older, larger stamp: less progress, never a wrong value), and the pass AFTER this launch runs every tile once from an
 // all-tiles list -- the flood is at its fixpoint when the ordinary passes that follow say so.
-template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false, int SEAM = 0, bool PERSIST = false>
+template <int NW, bool CHUNKED, bool SCAN, bool LITE, bool SPLIT = false, int SEAM = 0, int PERSIST = 0>
 __global__ __launch_bounds__(64 * NW, SCAN ? 4 : 6) void k_relax(      // the scan variant trades occupancy (few tiles run there) for registers
 const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                                                       int H, int W, int tilesX, int tilesY, int otherX, int otherY,
@@ -473,7 +489,12 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   uint32_t *q_state = tile_list + RL_HDR + 2 * (size_t)list_cap;
   uint32_t *q_head = tile_list + RLQ_HEAD, *q_tail = tile_list + RLQ_TAIL;
   uint32_t *q_pending = tile_list + RLQ_PENDING, *q_done = tile_list + RLQ_DONE;
-  __shared__ uint32_t s_qtile;
+  __shared__ uint32_t s_qtile, s_qbucket, s_handoff;
+  __shared__ uint32_t s_sidemin[4];      // PERSIST == 2: the smallest new stamp that matters across the top / bottom / left / right border
+  uint32_t *pq_avail = tile_list + pq_base(list_cap);
+  const uint32_t pq_bw = pq_words_per_bucket((uint32_t)(tilesX * tilesY));
+  uint32_t *pq_bits = pq_avail + PQ_HDR;
+  const uint32_t pq_shift = pq_shift_of(max_level);
   unsigned long long q_t0 = 0;
   uint32_t q_wait = 0, q_polls = 0;
 #ifdef WS_TUNING
@@ -535,7 +556,7 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
       if (!run) return;
     }
   }
-  if (threadIdx.x == 0) s_ncand = 0;      // (read again only after the first tile's barriers)
+  if (threadIdx.x == 0) { s_ncand = 0; if (PERSIST == 2) s_handoff = 0; }      // (read again only after the first tile's barriers)
   // Wave 0, all lanes: one "queued for pass p" exchange per candidate (a tile enters a list once: whoever finds the old
   // mark adds it), one ticket for the new entries of all of them.
   auto append_flush = [&]() {
@@ -558,7 +579,91 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   };
   for (;;) {
   uint32_t q_tile = 0;
-  if (PERSIST) {
+  if (PERSIST == 2) {
+    if (threadIdx.x < 64 && s_handoff != 0u) {      // (wave uniform) the run before this one took a tile it had announced itself
+      if (threadIdx.x == 0) { s_handoff = 0u; s_sidemin[0] = s_sidemin[1] = s_sidemin[2] = s_sidemin[3] = 0xFFFFFFFFu; }
+    } else if (threadIdx.x < 64) {
+      const int ln = (int)threadIdx.x;
+      const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+      const uint32_t nchunk = pq_bw >> 8;
+      uint32_t got = 0, got_b = 0, idle = 0;
+      for (;;) {
+        // one look at every bucket's count (lane b) and at the end flag (lane 63)
+        uint32_t av = 0;
+        if (ln < 32) av = __hip_atomic_load(pq_avail + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__shfl((int)av, PQ_B, 64) != 0) break;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ln < PQ_B && (int)av > 0);
+        // (every turn of this loop checks the clock: whatever goes wrong with counts or bits, the end flag is seen a turn later)
+        if (ln == 0 && __builtin_amdgcn_s_memrealtime() - q_t0 > RLQ_BUDGET_TICKS) {
+          __hip_atomic_store(q_done, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(pq_avail + PQ_B, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // A look that ends without a tile -- nothing queued, or somebody else was quicker -- is followed by a pause that grows
+        // with the looks in a row: a thousand workers after the same few bits, each look nine memory requests to the same
+        // nine lines, held every load of the RUNNING tiles up behind them (a tile run 60 us instead of 15).  Work that
+        // appears is found by whoever looks next, so the delay is the pause divided by the number of idle workers.
+        auto pause = [&]() {
+          ++q_polls;
+          ++idle;
+          // ... and with the worker's number: sixteen look every 3 us, forty-eight every 14, the rest every 54 -- a front that
+          // is a chain of tile runs is followed by the worker that runs it (the hand-off at the end of a run), and a backlog
+          // that lasts is found by everybody within one long pause
+          const int reps = (use_list & 2) ? 1 : (blockIdx.x < 16u ? 1 : (blockIdx.x < 64u ? 4 : 16));
+          if (use_list & 4) __builtin_amdgcn_s_sleep(2);
+          else if (idle < 3u) __builtin_amdgcn_s_sleep(8);
+          else if (idle < 6u) __builtin_amdgcn_s_sleep(64);
+          else { for (int z = 0; z < reps; ++z) __builtin_amdgcn_s_sleep(127); }
+        };
+        if (m == 0) { pause(); continue; }
+        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+        uint32_t *bm = pq_bits + (size_t)b * pq_bw;
+        for (uint32_t cc = 0; cc < nchunk; ++cc) {
+          const uint32_t c = (cc + blockIdx.x) % nchunk;      // (workers start in different chunks of a long bitmap)
+          u32x4_t v;
+          coh_load4(v, bm + c * 256u + (uint32_t)ln * 4u);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+          unsigned long long mm = __builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0u);
+          if (mm == 0) continue;
+          // workers that look at the same moment take different bits: the k-th lane that has any
+          int k = (int)(blockIdx.x % (uint32_t)__popcll(mm));
+          while (k-- > 0) mm &= mm - 1ull;
+          const int sel = (int)__builtin_ctzll(mm);
+          uint32_t t1 = 0, tb = 0;
+          if (ln == sel) {
+            const int j = v.x ? 0 : (v.y ? 1 : (v.z ? 2 : 3));
+            const uint32_t wv = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+            const uint32_t bit = wv & (0u - wv);
+            const uint32_t wi = c * 256u + (uint32_t)ln * 4u + (uint32_t)j;
+            if (atomicAnd(bm + wi, ~bit) & bit) {      // the bit is mine
+              atomicSub(pq_avail + b, 1u);
+              const uint32_t t = (wi << 5) + (uint32_t)__builtin_ctz(bit);
+              // not running -> running, every waiting bit taken with it: what they announced was stored before they were set,
+              // and this run loads after this exchange.  Running already (a stale bit): that run's end looks at the bits.
+              const uint32_t so = atomicMax(&q_state[t], PQ_RUNNING);
+              if (!(so & PQ_RUNNING)) {
+                if (so == 0u) atomicAdd(q_pending, 1u);      // (a stale bit of an idle tile: it runs once for nothing)
+                t1 = t + 1u;
+                tb = so ? (uint32_t)__builtin_ctz(so) : b;
+              }
+            }
+          }
+          got = (uint32_t)__shfl((int)t1, sel, 64);
+          got_b = (uint32_t)__shfl((int)tb, sel, 64);
+          break;      // taken, or somebody else was quicker: look at the counts again
+        }
+        if (got) break;
+        pause();
+      }
+      if (ln == 0) {
+        q_wait += (uint32_t)(__builtin_amdgcn_s_memrealtime() - w0);
+        s_qtile = got;
+        s_qbucket = got_b;
+        s_sidemin[0] = s_sidemin[1] = s_sidemin[2] = s_sidemin[3] = 0xFFFFFFFFu;
+      }
+    }
+    __syncthreads();
+    q_tile = s_qtile;
+  } else if (PERSIST) {
     if (threadIdx.x == 0) {
       unsigned long long v = 0;
       if (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -588,6 +693,8 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     }
     __syncthreads();
     q_tile = s_qtile;
+  }
+  if (PERSIST) {
     if (q_tile == 0) {           // workgroup uniform: the queue has run dry (or the time budget is spent)
       if (threadIdx.x == 0) {
         atomicAdd(tile_list + RLQ_WAIT, q_wait);
@@ -955,15 +1062,18 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
     // late tile runs changed nothing at all (tools/sim_tile_schedule.c, SIM_CHANGED): flagged by a neighbour whose front
     // had not caught up with theirs.
     auto matters = [](uint32_t before, uint32_t now, uint32_t across) { return before != now && now + 1u < across; };
+    auto least = [](uint32_t before, uint32_t now, uint32_t across) { return before != now && now + 1u < across ? now : 0xFFFFFFFFu; };      // (PERSIST == 2: the queue's order)
     if (band == 0) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[0][xl * RX_P]);
       const u32x4_t a = *reinterpret_cast<const u32x4_t *>(&sRow[0][xl * RX_P]);      // the halo row above, as loaded
       if (matters(o.x, T[0][0], a.x) || matters(o.y, T[0][1], a.y) || matters(o.z, T[0][2], a.z) || matters(o.w, T[0][3], a.w)) e |= qbit | (row_counts ? 64u : 0u);
+      if (PERSIST == 2 && (e & 64u)) atomicMin(&s_sidemin[0], min(min(least(o.x, T[0][0], a.x), least(o.y, T[0][1], a.y)), min(least(o.z, T[0][2], a.z), least(o.w, T[0][3], a.w))));
     }
     if (band == NB - 1) {
       const u32x4_t o = *reinterpret_cast<const u32x4_t *>(&sInitRow[1][xl * RX_P]);
       const u32x4_t a = *reinterpret_cast<const u32x4_t *>(&sRow[2 * NB + 1][xl * RX_P]);      // the halo row below
       if (matters(o.x, T[3][0], a.x) || matters(o.y, T[3][1], a.y) || matters(o.z, T[3][2], a.z) || matters(o.w, T[3][3], a.w)) e |= qbit | (row_counts ? 128u : 0u);
+      if (PERSIST == 2 && (e & 128u)) atomicMin(&s_sidemin[1], min(min(least(o.x, T[3][0], a.x), least(o.y, T[3][1], a.y)), min(least(o.z, T[3][2], a.z), least(o.w, T[3][3], a.w))));
     }
     if (SEAM == 2) {
       // a lane pair raises its own flags: the anchored tile that holds this lane's columns (left of the seam for the even
@@ -984,6 +1094,12 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
 #pragma unroll
       for (int r = 0; r < RX_P; ++r)
         if (matters(sInitCol[xl == 0 ? 0 : 1][band * RX_P + r], T[r][xl == 0 ? 0 : 3], xl == 0 ? Lh[r] : Rh[r])) e |= qbit | (xl == 0 ? 256u : 512u);      // (Lh of a row's first lane, Rh of its last: the halo column)
+      if (PERSIST == 2 && (e & (256u | 512u))) {
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < RX_P; ++r) m = min(m, least(sInitCol[xl == 0 ? 0 : 1][band * RX_P + r], T[r][xl == 0 ? 0 : 3], xl == 0 ? Lh[r] : Rh[r]));
+        atomicMin(&s_sidemin[xl == 0 ? 2 : 3], m);
+      }
     }
   }
   // (SEAM 2, a slice that stopped at its round cap: also the lanes that changed nothing ask for their tile's re-run)
@@ -1042,9 +1158,24 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
                               (ed & 256u) != 0u && tile_x > 0, (ed & 512u) != 0u && tile_x + 1 < tilesX};
         const uint32_t who[5] = {(uint32_t)t, (uint32_t)(t - tilesX), (uint32_t)(t + tilesX), (uint32_t)(t - 1), (uint32_t)(t + 1)};
         uint32_t n = s_ncand;
+        if (PERSIST == 2) {
+          // the bucket of what I announce: the level of the smallest stamp that matters across that side; for myself (I
+          // stopped at the round cap) the lowest of them and of the bucket I ran from
+          uint32_t bk[5];
+          bk[0] = s_qbucket;
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-          if (want[k]) s_cand[n++] = who[k];
+          for (int k = 1; k < 5; ++k) {
+            bk[k] = min(s_sidemin[k - 1] >> pq_shift, (uint32_t)(PQ_B - 1));
+            if (want[k]) bk[0] = min(bk[0], bk[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (want[k]) s_cand[n++] = who[k] | (bk[k] << 24);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (want[k]) s_cand[n++] = who[k];
+        }
         s_ncand = n;
       }
       pf.any_change[stripe] = 1u;
@@ -1056,6 +1187,72 @@ const uint8_t *__restrict__ img, size_t img_stride, uint32_t *keys,
   }
   WS_STAMP(3);
   WS_QPHASE(2);
+  if (PERSIST == 2) {
+    __syncthreads();      // thread 0's candidates (s_cand, s_ncand: the append_next block above) are there
+    if (tid < 64) {
+      const uint32_t self = (uint32_t)tile, n = s_ncand;
+      // my own entry (a run that stopped at its round cap) is lane 0's first business: its bit, then "not running any more"
+      // in one more exchange that tells me what was announced while I ran
+      const bool mine = (uint32_t)lane < n;
+      const uint32_t cw = mine ? s_cand[lane] : 0u;
+      const uint32_t cand = cw & 0x00FFFFFFu, cb = cw >> 24;      // (relax_pass: the queue is not used on planes of 2^24 tiles)
+      const bool other = mine && cand != self;
+      // Hand-off: the announced tile of the lowest bucket, if that is no higher than the bucket I ran from (the front I am
+      // following), is MY next tile -- one exchange "not running -> running" instead of its bit, its count, some worker's
+      // look, claim and exchange: five memory round trips off every hop of a flood that is a chain of tile runs.
+      // (Asking the counts instead -- "nothing waits below it", a look issued before the stores -- cost more than it found:
+      // one more request per run to the line every worker's counts live on, 4.98 -> 5.32 ms at correlation 64 px.)
+      uint32_t pick = other && (cb <= s_qbucket || (use_list & 16)) && !(use_list & 8) ? (cb << 8) | (uint32_t)lane : 0xFFFFu;
+#pragma unroll
+      for (int k = 1; k < 8; k <<= 1) pick = min(pick, (uint32_t)__shfl_xor((int)pick, k, 64));      // (candidates sit in lanes 0 .. 4)
+      pick = (uint32_t)__shfl((int)pick, 0, 64);
+      const bool hand = pick != 0xFFFFu && (pick & 0xFFu) == (uint32_t)lane;
+      uint32_t old = 0;
+      bool taken = false;
+      if (hand) {
+        old = atomicMax(&q_state[cand], PQ_RUNNING);
+        taken = !(old & PQ_RUNNING);      // idle (old == 0: mine to count) or queued (its bit goes stale): it is mine now
+      }
+      if (other && !taken) old = atomicOr(&q_state[cand], 1u << cb);
+      // idle: mine to queue (and to count); queued in a higher bucket: mine to queue lower, and its old bit goes;
+      // queued at or below mine: nothing; running: announced, its run's end queues it
+      bool push = other && !taken && !(old & PQ_RUNNING) && (old & ((2u << cb) - 1u)) == 0u;
+      const bool fresh = (push || taken) && old == 0u;
+      if (taken) { s_handoff = 1u; s_qtile = cand + 1u; s_qbucket = cb; }
+      uint32_t pb = cb, pt = cand;
+      uint32_t left = 0;
+      if (lane == 63) {      // (never a candidate's lane: a run announces five tiles at most)
+        const uint32_t c0 = s_cand[0];
+        if (n != 0u && (c0 & 0x00FFFFFFu) == self) atomicOr(&q_state[self], 1u << (c0 >> 24));
+        left = atomicAnd(&q_state[self], ~PQ_RUNNING) & ~PQ_RUNNING;
+        if (left) { push = true; pb = (uint32_t)__builtin_ctz(left); pt = self; }
+      }
+      const uint32_t n_fresh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+      if (lane == 63) {
+        // counted before anyone can take them; my own run leaves the count in the same add
+        const int net = (int)n_fresh - (left ? 0 : 1);
+        if (net > 0) atomicAdd(q_pending, (uint32_t)net);
+        else if (net < 0 && atomicSub(q_pending, 1u) == 1u) {
+          __hip_atomic_store(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(pq_avail + PQ_B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_ncand = 0;
+#ifdef WS_TUNING
+        atomicAdd(tile_list + RLQ_RUNS, 1u);
+#endif
+      }
+      if (push) {
+        const uint32_t bit = 1u << (pt & 31u);
+        if (!(atomicOr(pq_bits + (size_t)pb * pq_bw + (pt >> 5), bit) & bit)) atomicAdd(pq_avail + pb, 1u);
+        if (pt != self && old != 0u) {      // lowered: the bit of its former bucket
+          const uint32_t ob = (uint32_t)__builtin_ctz(old);
+          if (atomicAnd(pq_bits + (size_t)ob * pq_bw + (pt >> 5), ~bit) & bit) atomicSub(pq_avail + ob, 1u);
+        }
+      }
+    }
+    WS_QPHASE(3);
+    continue;
+  }
   if (PERSIST) {
     __syncthreads();      // thread 0's candidates (s_cand, s_ncand: the append_next block above) are there
     if (tid < 64) {
@@ -1177,12 +1374,16 @@ __global__ __launch_bounds__(256) void k_relax_list_regrid(int H, int W, int til
   if (todo == 0) return;
   uint32_t base = 0;
   if (lane == 0) {
-    base = atomicAdd(&tile_list[persist ? RLQ_TAIL : (pass & 3u)], (uint32_t)__popcll(todo));
+    base = atomicAdd(&tile_list[persist ? RLQ_TAIL : (pass & 3u)], (uint32_t)__popcll(todo));      // (persist == 2: a count for the diagnostics)
     if (persist) atomicAdd(&tile_list[RLQ_PENDING], (uint32_t)__popcll(todo));
   }
   base = __shfl(base, 0, 64);
   const uint32_t idx = base + (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
-  if (run && persist) reinterpret_cast<unsigned long long *>(tile_list + RL_HDR)[idx] = ((unsigned long long)(idx + 1u) << 32) | (uint32_t)t;
+  if (persist == 2) {      // the queue in flood order: everything starts in bucket 0 (these 64 tiles are two words of its bitmap, this wave's alone)
+    uint32_t *avail = tile_list + pq_base(list_cap);
+    if (lane == 0) atomicAdd(avail, (uint32_t)__popcll(todo));
+    if ((lane & 31) == 0) (avail + PQ_HDR)[(first >> 5) + (lane >> 5)] = (uint32_t)(todo >> (lane & 32));
+  } else if (run && persist) reinterpret_cast<unsigned long long *>(tile_list + RL_HDR)[idx] = ((unsigned long long)(idx + 1u) << 32) | (uint32_t)t;
   else if (run) tile_list[RL_HDR + (pass & 1u) * (size_t)list_cap + idx] = (uint32_t)t;
 }
 
@@ -1197,7 +1398,11 @@ __global__ __launch_bounds__(256) void k_relax_list_all(int H, int W, int tilesX
 }
 
 // words of scratch relax_pass wants for its tile lists
-size_t relax_list_words(int h, int w) { return RL_HDR + 3 * relax_tiles(h, w) + 64; }      // header, two entry arrays, queued marks (+ dummies)
+// header, two entry arrays, queued marks (+ dummies); the persistent pass's buckets: counts (a line each), bitmaps
+size_t relax_list_words(int h, int w) {
+  const uint32_t tiles = (uint32_t)relax_tiles(h, w);
+  return pq_base(tiles) + PQ_HDR + (size_t)PQ_B * pq_words_per_bucket(tiles);
+}
 
 // capacity of ONE of the two edge-stamp arrays: the shifted grid has one more row and column; the 128 x 64 grid of the
 // same-grid passes has its own count
@@ -1250,7 +1455,7 @@ bool relax_uses_seam_repair(int h, int w, bool seed_bits, int slice_h, bool padd
 hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint32_t *keys, int h, int w,
                       uint32_t max_level, uint32_t pass, uint32_t *stamps, PassFlags pf, uint32_t max_iters,
                       const uint32_t *seed_labels, bool seed_bits, int slice_h, bool carry_checked_later, bool padded,
-                      uint32_t *tile_list, size_t seam_min_px, bool persistent_pass) {
+                      uint32_t *tile_list, size_t seam_min_px, int persistent_pass) {
   const int th = RX_NW * RX_P;
   const int pad = padded ? 1 : 0;
   // A carry out of the 24-bit ring field leaves a finite stamp with ring 0 in the plane (and nothing ever lowers it: the
@@ -1396,19 +1601,32 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         // 13-17 us either way (4 us of loads past L2, 4-8 of scan rounds, 3 of write-through stores, 2 of queue atomics), the
         // queue saves the launch gaps and the tails of the passes and pays for them with a sixth more tile runs (no pass
         // barrier: a tile runs on the first flag instead of on all flags of a pass) and with slower hops along a thin front.
-        static const bool force_persist = tuning_env("WS_RELAX_PERSIST") != nullptr;      // A/B knob, tools/ only
-        const bool persist = (persistent_pass || force_persist) && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
-                             ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap;
+        const int persist_mode = tuning_env("WS_RELAX_PERSIST") ? atoi(tuning_env("WS_RELAX_PERSIST")) : persistent_pass;      // (A/B knob, tools/ only)
+        const bool persist = persist_mode != 0 && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
+                             ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap && list_cap < (1u << 24);
         if (persist) {
+          const bool in_order = persist_mode == 2;      // buckets in flood order (PERSIST == 2) instead of the first-come ring
           hipError_t e = hipMemsetAsync(tile_list + RL_HDR, 0, 2 * (size_t)list_cap * sizeof(uint32_t), s);      // the ring: no entry yet
           if (e == hipSuccess) e = hipMemsetAsync(tile_list + 8, 0, (RL_HDR - 8) * sizeof(uint32_t), s);      // counters (and diagnostics)
+          if (e == hipSuccess && in_order)
+            e = hipMemsetAsync(tile_list + pq_base(list_cap), 0, (PQ_HDR + (size_t)PQ_B * pq_words_per_bucket(list_cap)) * sizeof(uint32_t), s);
           if (e != hipSuccess) return e;
-          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, 1);
+          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, in_order ? 2 : 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
-          k_relax<RX_SNW, true, true, true, true, 0, true><<<std::min<unsigned>(RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy)), 64 * RX_SNW, 0, s>>>(
-              img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf,
-              tuning_env("WS_RELAX_PERSIST_CAP") ? (uint32_t)atoi(tuning_env("WS_RELAX_PERSIST_CAP")) : RLQ_ROUND_CAP, nullptr, 0, sh,
-              check_carry, pad, tile_list, tuning_env("WS_RELAX_PERSIST_MODE") ? atoi(tuning_env("WS_RELAX_PERSIST_MODE")) : 0, 1, 1, list_cap, 1);
+          // In flood order: one worker per CU.  Two (all that are resident) run twice as long each, the rounds too -- a
+          // workgroup is one wave per SIMD, and two share their vector issue -- so nothing is gained where all are busy, and
+          // where most are idle their looks at the counts are in the way: 8192^2 smooth maps, correlation 4 / 16 / 64 / 256 px,
+          // 3.89 / 7.75 / 5.73 / 4.14 ms with 512 workers, 3.82 / 7.22 / 4.98 / 3.98 with 256 (gpurun_out/r3z).
+          const unsigned workers = tuning_env("WS_RELAX_PERSIST_WORKERS") ? (unsigned)atoi(tuning_env("WS_RELAX_PERSIST_WORKERS"))
+                                                                          : std::min<unsigned>(in_order ? RX_LIST_GRID / 2 : RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy));
+          const uint32_t cap = tuning_env("WS_RELAX_PERSIST_CAP") ? (uint32_t)atoi(tuning_env("WS_RELAX_PERSIST_CAP")) : RLQ_ROUND_CAP;
+          const int mode = tuning_env("WS_RELAX_PERSIST_MODE") ? atoi(tuning_env("WS_RELAX_PERSIST_MODE")) : 0;
+          if (in_order)
+            k_relax<RX_SNW, true, true, true, true, 0, 2><<<workers, 64 * RX_SNW, 0, s>>>(img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, cap,
+                                                                                         nullptr, 0, sh, check_carry, pad, tile_list, mode, 1, 1, list_cap, 1);
+          else
+            k_relax<RX_SNW, true, true, true, true, 0, 1><<<workers, 64 * RX_SNW, 0, s>>>(img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, cap,
+                                                                                         nullptr, 0, sh, check_carry, pad, tile_list, mode, 1, 1, list_cap, 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
           if (tuning_env("WS_RELAX_PERSIST_DIAG")) {      // tools/ only: what the workers did
             uint32_t hd[RL_HDR];

@@ -350,17 +350,20 @@ def test_segment_large_smooth_fields_long_range(pkg, shape, octaves, few_seeds):
     assert st["relax_passes"] >= 8           # the scan-capable kernel variant ran (passes >= 4)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("shape,octaves,few_seeds", [((1100, 1600), 6, False), ((900, 2048), 7, True), ((1500, 640), 7, True), ((2100, 300), 5, False)])
-def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, few_seeds):
+def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, few_seeds, mode):
     # ws_ctx_set_persistent_pass: the first same-grid pass of a long-range flood as ONE launch with a device-side tile queue
-    # (k_relax, PERSIST).  Opt-in; the labels must be the oracle's whatever order the queue runs the tiles in.
+    # (k_relax, PERSIST), first come (1) or in flood order (2: buckets by level, a run hands itself the tile it announced).
+    # Opt-in; the labels must be the oracle's whatever order the queue runs the tiles in.
     img = cases.smooth_field(shape[0], shape[1], 11 + octaves, octaves=octaves)
     seeds = ol.find_local_minima(img)
     if few_seeds:
         seeds = seeds[::max(len(seeds) // 3, 1)]
     ws = _seg(pkg)
     c = ws._ctx()
-    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 1) == 0
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 3) == pkg._ffi.WS_ERR_BAD_ARG
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, mode) == 0
     got = ws.transform(img, seeds)
     st = c.stats()
     assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
@@ -373,7 +376,7 @@ def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, f
         x = slice(-6, -3) if (r // 10) % 2 == 0 else slice(3, 6)
         corridor[r:r + 11, x] = 7
     cs = np.array([[5, 4]], dtype=np.uint64)
-    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 1) == 0
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, mode) == 0
     got = ws.transform(corridor, cs)
     assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
     assert (got == ol.segment_arrival(corridor, cs)).all()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ONE smooth-field segmenting transform after two warm-ups, for `rocprofv3 --kernel-trace` (tools/trace_passes.py lists
-the last transform's launches).  usage: exp_smooth_trace.py [N=8192] [corr=64] [seed_stride=1]"""
+the last transform's launches).  usage: exp_smooth_trace.py [N=8192] [corr=64] [seed_stride=1] [persistent_pass=0]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,9 @@ corr = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 stride = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 torch.cuda.set_stream(torch.cuda.Stream(0))
 eng = dev.DeviceEngine(0)
+if len(sys.argv) > 4:
+    pkg = importlib.import_module("rustronomy_watershed_amd")
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(eng.ctx.handle, int(sys.argv[4])) == 0
 g = torch.Generator(device="cuda").manual_seed(3)
 low = torch.rand((1, 1, n // corr + 2, n // corr + 2), device="cuda", generator=g)
 up = torch.nn.functional.interpolate(low, size=(n, n), mode="bicubic", align_corners=False)[0, 0]

@@ -239,6 +239,7 @@ int main(int argc, char **argv) {
     const int prio = strcmp(getenv("SIM_QUEUE"), "prio") == 0;
     const int W = getenv("SIM_WORKERS") ? atoi(getenv("SIM_WORKERS")) : 512;
     const int shift = getenv("SIM_PRIO_SHIFT") ? atoi(getenv("SIM_PRIO_SHIFT")) : 24;
+    const int tie_rand = getenv("SIM_TIE") && strcmp(getenv("SIM_TIE"), "rand") == 0;
     double c_fixed = 8.0, c_round = 3.0;
     if (getenv("SIM_COST")) sscanf(getenv("SIM_COST"), "%lf,%lf", &c_fixed, &c_round);
     const size_t T = (size_t)tx * ty;
@@ -258,7 +259,9 @@ int main(int argc, char **argv) {
           if (state[t] != 1) continue;
           if (best == T) { best = t; continue; }
           const uint32_t a = prio ? pending[t] >> shift : 0, b = prio ? pending[best] >> shift : 0;
-          if (a < b || (a == b && seq[t] < seq[best])) best = t;
+          /* SIM_TIE=rand: among equals any tile (a bitmap per bucket has no order), else the one queued first */
+          const uint64_t sa = tie_rand ? (seq[t] * 0x9E3779B97F4A7C15ull) >> 20 : seq[t], sb = tie_rand ? (seq[best] * 0x9E3779B97F4A7C15ull) >> 20 : seq[best];
+          if (a < b || (a == b && sa < sb)) best = t;
         }
         const long r0 = g_rounds;
         const int i = (int)(best % tx), j = (int)(best / tx);
