@@ -158,13 +158,67 @@ def end_to_end(pkg, eng, H, W, runs=5):
     t32.sort()
     med32 = t32[len(t32) // 2]
     same = bool((labels32 == labels.astype(np.uint32)).all())
+    # ... and the README's call pair (lib.rs:73-86) as one call, ws_segment_minima: no seed list in either direction
+    def timed(fn, out):
+        ts = []
+        for i in range(runs + 2):
+            t0 = time.perf_counter()
+            rc = fn(ctx.handle, img.ctypes.data, H, W, W, ctypes.byref(opt), out.ctypes.data, None, 0, ctypes.byref(n2))
+            dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            if i >= 2:
+                ts.append(dt)
+        ts.sort()
+        return ts[len(ts) // 2]
+    n2 = ctypes.c_size_t(0)
+    lab_m = np.zeros((H, W), dtype=np.uint64)
+    med_m = timed(ffi.lib().ws_segment_minima, lab_m)
+    same_m = bool((lab_m == labels).all()) and n2.value == n.value
+    med_m32 = timed(ffi.lib().ws_segment_minima_u32, labels32)
+    t0 = time.perf_counter()
+    rc = ffi.lib().ws_find_local_minima(ctx.handle, img.ctypes.data, H, W, W, seeds.ctypes.data, cap, ctypes.byref(n))
+    ms_minima = (time.perf_counter() - t0) * 1e3
+    assert rc == 0, rc
     ctx.close()
+    pair = {"entry_point": "ws_segment_minima (find_local_minima + transform as one call: u8 image in, u64 labels out, no seed list)",
+            "ms": round(med_m * 1e3, 3), "bytes_over_pcie": int(H * W * 9), "pcie_GBps": round(H * W * 9 / med_m / 1e9, 1),
+            "equal_to_the_two_calls": same_m, "ms_u32_labels": round(med_m32 * 1e3, 3),
+            "the_two_calls_ms": round(ms_minima + med * 1e3, 3), "ws_find_local_minima_ms": round(ms_minima, 3)}
     return {"entry_point": "ws_segment (host ABI: pageable u8 image + u64 seed pairs in, u64 labels out)",
+            "call_pair_as_one_call": pair,
             "ms": round(med * 1e3, 3), "Mpixels_per_s": round(H * W / med / 1e6, 1), "bytes_over_pcie": int(nbytes),
             "pcie_GBps": round(nbytes / med / 1e9, 1), "runs": len(times), "host_buffers": "reused, touched",
             "u32_labels": {"entry_point": "ws_segment_u32 (the same, u32 labels out)", "ms": round(med32 * 1e3, 3),
                            "bytes_over_pcie": int(nbytes - H * W * 4), "pcie_GBps": round((nbytes - H * W * 4) / med32 / 1e9, 1), "equal_to_u64_labels": same},
             "note": "the link is the bound: pageable copies run at the box's 53-54 GB/s either way, the transform is 0.56 ms of it"}
+
+
+def call_pair_device(eng, torch, H, W, runs=9):
+    """The README's call pair on device-resident buffers (lib.rs:73-86): find_local_minima + transform as two calls, and as
+    ONE (ws_segment_minima_device: the seed tables come out of the minima kernels, no list is written).  One context,
+    nothing else in flight."""
+    img = eng.random_field(H, W, 1)
+    labels = torch.empty((H, W), dtype=torch.int32, device=eng.device)
+
+    def med(fn):
+        ts = []
+        for i in range(runs + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+    two = med(lambda: eng.segment(img, eng.find_local_minima(img), out=labels))
+    ref = labels.clone()
+    one = med(lambda: eng.segment_minima(img, out=labels))
+    same = bool((labels == ref).all().item())
+    one_list = med(lambda: eng.segment_minima(img, out=labels, want_seeds=True))
+    return {"ms_two_calls": round(two, 4), "ms_one_call": round(one, 4), "ms_one_call_with_the_list": round(one_list, 4), "same_labels": same,
+            "note": "two calls: ws_find_local_minima_device (writes the 56 MiB list, reads its count back) + ws_segment_device (k_seed_tables searches "
+                    "and checks the list); one call: count, scan, compaction write the seed tables directly"}
 
 
 def secondary_smooth(eng, torch, size, corr=64, runs=3):
@@ -627,6 +681,8 @@ def run(args):
             # the same at other correlation lengths (4 px: ~680 k seeds, short floods; 256 px: one seed, one flood over the plane)
             out["secondary"]["other_correlation_lengths"] = {
                 str(c): {k: v for k, v in secondary_smooth(eng, torch, H, corr=c).items() if k in ("ms", "relax_passes")} for c in (4, 16, 256)}
+            torch.cuda.empty_cache()
+            out["call_pair"] = call_pair_device(eng, torch, H, W)
             torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(pkg, eng, H, W)
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1, args.cpu_runs, 0 if args.no_cpu_full or cfg != "headline" else H) if (world == 1 and args.cpu_size > 0 and not args.no_extras) else None

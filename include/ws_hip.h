@@ -202,6 +202,22 @@ int ws_segment_u32(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t r
                    const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
                    uint32_t *out_labels);
 
+/* The README's call pair as ONE call (lib.rs:73-86: `let mins = ws.find_local_minima(img); ws.transform(img, &mins)`):
+ * the seeds are find_local_minima(img) (lib.rs:1178-1197, in its row-major order: colour i + 1 for its i-th entry) and the labels
+ * are transform's for that list.  The list never has to exist: with the fused engine, no edge correction and w % 32 == 0 the
+ * seed tables come out of the minima kernels themselves; otherwise the two calls run one after the other.  seeds_rc (cap
+ * pairs, may be NULL with cap 0) receives the list when the caller wants it; *n_seeds its length.  WS_ERR_CAPACITY when
+ * cap > 0 is too small -- the labels are complete then, the list is cut.  8192^2 host form: 117 MB of seed pairs less each
+ * way over PCIe than ws_find_local_minima + ws_segment. */
+int ws_segment_minima(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride, const ws_options *opt,
+                      uint64_t *out_labels, uint64_t *seeds_rc, size_t cap, size_t *n_seeds);
+int ws_segment_minima_u32(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride, const ws_options *opt,
+                          uint32_t *out_labels, uint64_t *seeds_rc, size_t cap, size_t *n_seeds);
+/* ... on device-resident buffers: d_labels h x w (padded with edge correction) uint32_t, d_seeds_rc cap (row, col) uint32_t
+ * pairs or NULL. */
+int ws_segment_minima_device(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride, const ws_options *opt,
+                             uint32_t *d_labels, uint32_t *d_seeds_rc, size_t cap, size_t *n_seeds);
+
 /* Watershed::transform_with_hook for SegmentingWatershed (lib.rs:1638-1808): cb is called
  * after every level 0..=max with the label plane of that level; transform_history
  * (lib.rs:1824-1835) is this with a copying callback.  out_labels may be NULL. */

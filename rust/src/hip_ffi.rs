@@ -141,6 +141,12 @@ extern "C" {
         seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, out_labels: *mut u64) -> c_int;
     pub fn ws_segment_u32(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
         seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, out_labels: *mut u32) -> c_int;
+    pub fn ws_segment_minima(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        opt: *const ws_options, out_labels: *mut u64, seeds_rc: *mut u64, cap: usize, n_seeds: *mut usize) -> c_int;
+    pub fn ws_segment_minima_u32(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
+        opt: *const ws_options, out_labels: *mut u32, seeds_rc: *mut u64, cap: usize, n_seeds: *mut usize) -> c_int;
+    pub fn ws_segment_minima_device(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize,
+        opt: *const ws_options, d_labels: *mut u32, d_seeds_rc: *mut u32, cap: usize, n_seeds: *mut usize) -> c_int;
     pub fn ws_segment_with_hook(ctx: *mut ws_ctx, img: *const u8, h: usize, w: usize, row_stride: usize,
         seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, cb: ws_level_cb, user: *mut c_void,
         out_labels: *mut u64) -> c_int;

@@ -100,6 +100,9 @@ SIGNATURES = {
     "ws_find_local_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
     "ws_segment": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_segment_u32": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
+    "ws_segment_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.POINTER(Options), vp, vp, sz, szp]),
+    "ws_segment_minima_u32": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.POINTER(Options), vp, vp, sz, szp]),
+    "ws_segment_minima_device": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.POINTER(Options), vp, vp, sz, szp]),
     "ws_segment_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
     "ws_merge_with_hook": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, vp, vp]),
     "ws_transform_to_list": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz,

@@ -380,6 +380,21 @@ class SegmentingWatershed(_Transform):
         ctx.check(rc)
         return out
 
+    def transform_from_minima(self, input, want_seeds=False, labels_u32=False):
+        """`self.transform(input, &self.find_local_minima(input))` -- the README's call pair, lib.rs:73-86 -- as ONE call of the
+        library (ws_segment_minima): the seed list never crosses PCIe unless want_seeds.  Not a method of the reference."""
+        a, stride = _as_image(input)
+        h, w = a.shape
+        ctx = self._ctx()
+        out = np.empty(self._shape(a), dtype=np.uint32 if labels_u32 else np.uint64)
+        cap = ((max(h, 1) - 1) // 2 + 1) * ((max(w, 1) - 1) // 2 + 1) if want_seeds else 0
+        seeds = np.empty((max(cap, 1), 2), dtype=np.uint64) if want_seeds else None
+        n = ctypes.c_size_t(0)
+        fn = _ffi.lib().ws_segment_minima_u32 if labels_u32 else _ffi.lib().ws_segment_minima
+        ctx.check(fn(ctx.handle, a.ctypes.data, h, w, stride, ctypes.byref(self._opt), out.ctypes.data,
+                     seeds.ctypes.data if want_seeds else None, cap, ctypes.byref(n)))
+        return (out, seeds[: n.value].copy()) if want_seeds else out
+
 
 class MergingWatershed(_Transform):
     """lib.rs:1297-1562"""

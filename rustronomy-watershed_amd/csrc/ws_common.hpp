@@ -158,11 +158,12 @@ hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, cons
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded = false);
 
 // local maxima: count per 1024-px row segment, scan, write
-size_t minima_segments(int h, int w);       // count words (one per row)
+size_t minima_segments(int h, int w);       // count words (one per row and one per strip of rows)
 size_t minima_mask_bytes(int h, int w);     // nibble plane written by minima_count, read by minima_write
 hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts, uint8_t *nibbles);
-hipError_t exclusive_scan_u32(hipStream_t s, uint32_t *data, size_t n, uint32_t *total);
-hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *offsets, uint32_t *out_rc, size_t cap);
+hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *counts, uint32_t *total, uint32_t *out_rc, size_t cap,      // *total: the list's length
+                        uint32_t *mask = nullptr, uint32_t *word_base = nullptr,      // w % 32 == 0: the seed tables of this list (seed_tables' layout)
+                        uint32_t *zero_a = nullptr, size_t n_zero_a = 0, uint32_t *zero_b = nullptr, size_t n_zero_b = 0);
 hipError_t widen_pairs(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n_values);
 
 inline int tiles_of(int n) { return (n + TS - 1) / TS; }

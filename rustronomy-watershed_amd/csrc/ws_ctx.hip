@@ -233,7 +233,7 @@ void ws_ctx_destroy(ws_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->seeds64,
+  for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->min_counts, &c->min_nibbles, &c->seeds64,
                     &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->uf_death, &c->uf_sd, &c->alive, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -321,8 +321,7 @@ int ws_find_local_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_
   uint8_t *nibbles = (uint8_t *)c->aux.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
   HIP_TRY(c, minima_count(c->stream, d_img, stride, (int)h, (int)w, counts, nibbles));
-  HIP_TRY(c, exclusive_scan_u32(c->stream, counts, nseg, flags + FLAG_TOTAL));
-  HIP_TRY(c, minima_write(c->stream, nibbles, (int)h, (int)w, counts, d_out_rc, cap));
+  HIP_TRY(c, minima_write(c->stream, nibbles, (int)h, (int)w, counts, flags + FLAG_TOTAL, d_out_rc, cap));
   HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_TOTAL], flags + FLAG_TOTAL, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *n_found = c->pinned[FLAG_TOTAL];

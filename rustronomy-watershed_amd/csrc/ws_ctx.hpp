@@ -46,7 +46,7 @@ struct ws_ctx {
   std::string err;
   ws_stats stats{};
 
-  wsapi::DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack;
+  wsapi::DevBuf img, keys, labels, labels2, stamps, flags, seeds, seeds64, out64, counts, aux, seed_stack, min_counts, min_nibbles;
   wsapi::DevBuf uf_parent, uf_size, uf_hooked, uf_death, uf_sd, alive, px_items, edge_items, mflags, lakes, refs, seed_tab, tile_list;
   uint32_t *pinned = nullptr;      // FLAG_WORDS words of pinned host memory: the host's mirror of the flag block
   uint32_t *pinned_dev = nullptr;  // the same words as the device sees them (nullptr: not mapped, copies only)
@@ -87,11 +87,11 @@ struct ws_ctx {
     const void *img = nullptr, *seeds = nullptr, *labels = nullptr, *slice_first = nullptr, *tile_min = nullptr;
     size_t stride = 0, n_seeds = 0;
     int ph = 0, pw = 0, slice_h = 0;
-    bool padded = false;
+    bool padded = false, from_minima = false;
     uint32_t max_level = 0;
     uint64_t generation = 0;      // of the context's own buffers (buffer_generation)
     bool operator==(const GraphKey &o) const {
-      return generation == o.generation && img == o.img && seeds == o.seeds && labels == o.labels && slice_first == o.slice_first && tile_min == o.tile_min &&
+      return generation == o.generation && from_minima == o.from_minima && img == o.img && seeds == o.seeds && labels == o.labels && slice_first == o.slice_first && tile_min == o.tile_min &&
              stride == o.stride && n_seeds == o.n_seeds && ph == o.ph && pw == o.pw && slice_h == o.slice_h && padded == o.padded && max_level == o.max_level;
     }
   };
@@ -257,9 +257,11 @@ inline int refuse_if_in_flight(ws_ctx *c) {
 }
 
 // ws_segment.hip
+// (MinimaSeeds: the seeds are the image's own local minima, lib.rs:1178-1197 -- no list comes in; one goes out if asked for)
+struct MinimaSeeds { uint32_t *d_list; size_t cap; size_t found; };
 int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
                    const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted,
-                   int slice_h = 0, const uint32_t *slice_first = nullptr, bool padded = false);
+                   int slice_h = 0, const uint32_t *slice_first = nullptr, bool padded = false, MinimaSeeds *minima = nullptr);
 int run_fused(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
               const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool padded = false);
 

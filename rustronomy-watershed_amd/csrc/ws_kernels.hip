@@ -1380,134 +1380,222 @@ hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, cons
 
 // ---------------------------------------------------------- find_local_minima --------
 //
-// lib.rs:1178-1197: interior pixels whose 8 neighbours are all strictly smaller, emitted in row-major
-// order.  One workgroup per image row, 4 pixels per thread and step: the count pass also leaves the
-// 4-bit answer of every thread-step in a nibble plane, so that the ordered write (after an exclusive scan
-// of the per-row counts) does not read the image again.
+// lib.rs:1178-1197: interior pixels whose 8 neighbours are all strictly smaller, emitted in row-major order.
+// Two launches: the COUNT pass looks at the image once and leaves the 4-bit answer of every 4-pixel group in a nibble plane
+// and every row's place in the list (row counts, scanned by its last workgroup); the WRITE pass turns nibbles into list
+// entries -- and, when asked, into the seed side tables of that list (k_seed_tables' layout) -- without reading the image again.
+//
+// The count pass is vector-issue work (8192^2 random bytes: 73 us when every pixel took the max of its eight neighbours
+// byte by byte, ~37 instructions a pixel), so it computes in packed 16-bit pairs and reuses row maxima:
+//     h3[y][x] = max(r[y][x-1], r[y][x], r[y][x+1])      m2[y][x] = max(r[y][x-1], r[y][x+1])
+//     strict maximum at (y, x)  <=>  r[y][x] > max(h3[y-1][x], h3[y+1][x], m2[y][x])
+// a thread owns 4 columns of MIN_RS rows: per row 3 loads, 5 byte permutes, 6 packed maxima for h3 / m2 and 11 more
+// operations for the four answers -- ~6 a pixel.  Rows and columns outside the image are CLAMPED to the nearest one inside:
+// a pixel on the image border then meets its own value among its "neighbours" and can never be a strict maximum, which is
+// the reference's "interior only" (3 x 3 windows, lib.rs:1183) without a single mask.
 
 constexpr int SEG = 1024;            // pixels per workgroup step: 256 threads x 4
+constexpr int MIN_RS = 8;            // rows per workgroup of the count pass
+static_assert(MIN_RS == 8, "k_minima_count's strip sum and k_minima_write's offsets assume strips of eight rows");
 
-size_t minima_segments(int h, int w) { return (size_t)h; }                                    // one count per row
-size_t minima_mask_bytes(int h, int w) { return (size_t)h * ((w + SEG - 1) / SEG) * 256; }    // one nibble byte per thread-step
+size_t minima_segments(int h, int w) { return (size_t)h + (h + MIN_RS - 1) / MIN_RS + 1; }     // one count per row, one per strip of MIN_RS rows
+size_t minima_mask_bytes(int h, int w) { return (size_t)h * ((w + SEG - 1) / SEG) * 256; }    // one nibble byte per 4-pixel group
 
-// the six pixels x0-1 .. x0+4 of one row as bytes of a 64-bit word (clamped at the row ends: a clamped
-// byte only ever meets a pixel that is not interior)
-__device__ __forceinline__ unsigned long long row_window(const uint8_t *row, int W, int x0, bool fast) {
-  if (fast) {      // x0 >= 4, x0 + 8 <= W, dword-aligned row: three aligned loads, unconditional
-    const uint32_t p = *reinterpret_cast<const uint32_t *>(row + x0 - 4), c = *reinterpret_cast<const uint32_t *>(row + x0),
-                   n = *reinterpret_cast<const uint32_t *>(row + x0 + 4);
-    return (unsigned long long)(p >> 24) | ((unsigned long long)c << 8) | ((unsigned long long)(n & 0xFFu) << 40);
-  }
-  unsigned long long w = 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) w |= (unsigned long long)row[min(max(x0 - 1 + k, 0), W - 1)] << (8 * k);
-  return w;
+typedef unsigned short u16x2_m __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_m, a), __builtin_bit_cast(u16x2_m, b)));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_m, a), __builtin_bit_cast(u16x2_m, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_m, a), __builtin_bit_cast(u16x2_m, b)));
 }
 
-// bit k set when pixel (y, x0+k) is a strict 8-neighbour maximum of the interior; 1 <= y <= H-2
-__device__ __forceinline__ uint32_t maxima_mask4(const uint8_t *img, size_t stride, int W, int y, int x0, bool aligned) {
-  const bool fast = aligned && x0 >= 4 && x0 + 8 <= W;
-  const int xc = min(x0, max(W - 1, 0));
-  const unsigned long long t = row_window(img + (size_t)(y - 1) * stride, W, xc, fast);
-  const unsigned long long m = row_window(img + (size_t)y * stride, W, xc, fast);
-  const unsigned long long b = row_window(img + (size_t)(y + 1) * stride, W, xc, fast);
-  uint32_t tb[6], mb[6], bb[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { tb[k] = (uint32_t)(t >> (8 * k)) & 0xFFu; mb[k] = (uint32_t)(m >> (8 * k)) & 0xFFu; bb[k] = (uint32_t)(b >> (8 * k)) & 0xFFu; }
-  uint32_t mask = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {      // branch-free: max of the 8 neighbours, one compare
-    const uint32_t nb = max(max(max(tb[k], tb[k + 1]), max(tb[k + 2], mb[k])), max(max(mb[k + 2], bb[k]), max(bb[k + 1], bb[k + 2])));
-    const int x = x0 + k;
-    mask |= (uint32_t)((mb[k + 1] > nb) & (x >= 1) & (x < W - 1)) << k;
+// One row's contribution for the columns x0 .. x0+3: h3 and m2 of the pairs (x0, x0+1) and (x0+2, x0+3), and the pixels
+// themselves, every value in a 16-bit half.
+struct MinRow { uint32_t h01, h23, m01, m23, c01, c23; };
+
+// ALIGNED (kernel uniform: dword-aligned rows, W % 4 == 0): three dword loads at clamped offsets, unconditional -- a branch
+// per row between them made every row's loads wait for the row before (ten dependent round trips per thread: 50 us of
+// the kernel's 53) -- and the three groups that need other bytes (the row's first, its last, any beyond its end) patch
+// them in afterwards.
+struct MinRaw { uint32_t L, M, R; };      // the dwords left of, at and right of x0: bytes b0 = L[3], b1..b4 = M, b5 = R[0]
+
+template <bool ALIGNED>
+__device__ __forceinline__ MinRaw minima_load(const uint8_t *row, int W, int x0) {
+  MinRaw v;
+  if (ALIGNED) {
+    const uint32_t last = (uint32_t)(W - 4), o = min((uint32_t)x0, last);
+    v.L = *reinterpret_cast<const uint32_t *>(row + (o >= 4u ? o - 4u : 0u));
+    v.M = *reinterpret_cast<const uint32_t *>(row + o);
+    v.R = *reinterpret_cast<const uint32_t *>(row + min(o + 4u, last));
+  } else {
+    auto at = [&](int x) { return (uint32_t)row[min(max(x, 0), W - 1)]; };
+    v.L = at(x0 - 1) << 24;
+    v.M = at(x0) | (at(x0 + 1) << 8) | (at(x0 + 2) << 16) | (at(x0 + 3) << 24);
+    v.R = at(x0 + 4);
   }
-  return mask;
+  return v;
 }
 
+template <bool ALIGNED>
+__device__ __forceinline__ MinRow minima_row(MinRaw v, int W, int x0) {
+  uint32_t L = v.L, M = v.M, R = v.R;
+  if (ALIGNED) {
+    if (x0 == 0) L = M << 24;                                // the pixel left of the row's first: itself
+    if ((uint32_t)x0 >= (uint32_t)(W - 4)) R = M >> 24;      // ... right of its last: itself
+    if (x0 >= W) { L = 0u; M = 0u; R = 0u; }                 // a group beyond the row: all equal, no maximum
+  }
+  // pairs of neighbouring bytes, one per 16-bit half (v_perm_b32: selector 0-3 = bytes of the second operand, 4-7 = of the first, 0x0c = zero)
+  const uint32_t A = __builtin_amdgcn_perm(L, M, 0x0C000C07u);      // (b0, b1)
+  const uint32_t B = __builtin_amdgcn_perm(M, M, 0x0C010C00u);      // (b1, b2): the pixels x0, x0+1
+  const uint32_t C = __builtin_amdgcn_perm(M, M, 0x0C020C01u);      // (b2, b3)
+  const uint32_t D = __builtin_amdgcn_perm(M, M, 0x0C030C02u);      // (b3, b4): the pixels x0+2, x0+3
+  const uint32_t E = __builtin_amdgcn_perm(R, M, 0x0C040C03u);      // (b4, b5)
+  MinRow r;
+  r.m01 = pk_max(A, C);
+  r.m23 = pk_max(C, E);
+  r.h01 = pk_max(r.m01, B);
+  r.h23 = pk_max(r.m23, D);
+  r.c01 = B;
+  r.c23 = D;
+  return r;
+}
+
+// bit k: pixel x0 + k of row `mid` is a strict maximum of its 3 x 3 window
+__device__ __forceinline__ uint32_t minima_nibble(const MinRow &above, const MinRow &mid, const MinRow &below) {
+  const uint32_t n01 = pk_max(pk_max(above.h01, below.h01), mid.m01), n23 = pk_max(pk_max(above.h23, below.h23), mid.m23);
+  const uint32_t g01 = pk_min(pk_sub_sat(mid.c01, n01), 0x00010001u), g23 = pk_min(pk_sub_sat(mid.c23, n23), 0x00010001u);      // 1 where centre > neighbours
+  const uint32_t t = g01 | (g23 << 2);      // bits 0, 16, 2, 18
+  return (t | (t >> 15)) & 0xFu;
+}
+
+// A workgroup: MIN_RS rows of one 1024-pixel segment (a row strip per workgroup, all segments in turn: 16 waves per CU in
+// flight and 73 -> 53 us; this way 8192 workgroups at 8192^2).  Row counts are added up in counts[y], strip counts in
+// counts[H + strip]: eight atomics per address.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_minima_count(const uint8_t *__restrict__ img, size_t stride, int H, int W,
-                                                      uint32_t *counts, uint8_t *nibbles) {
-  __shared__ uint32_t s_wave[4];
-  const int y = blockIdx.x, segs = (W + SEG - 1) / SEG;
-  const bool row_ok = y >= 1 && y < H - 1;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(img) | stride) & 3u) == 0;
-  uint32_t c = 0;
-  for (int seg = 0; seg < segs; ++seg) {
-    const int x0 = seg * SEG + threadIdx.x * 4;
-    const uint32_t m = (row_ok && x0 < W) ? maxima_mask4(img, stride, W, y, x0, aligned) : 0u;
-    nibbles[((size_t)y * segs + seg) * 256 + threadIdx.x] = (uint8_t)m;
-    c += __popc(m);
+                                                      uint32_t *__restrict__ counts, uint8_t *__restrict__ nibbles) {
+  __shared__ uint32_t s_wave[4 * MIN_RS];
+  const int segs = (W + SEG - 1) / SEG;
+  const int seg = blockIdx.x % segs, y0 = (blockIdx.x / segs) * MIN_RS;
+  auto row_ptr = [&](int y) { return img + (size_t)min(max(y, 0), H - 1) * stride; };      // (workgroup uniform)
+  const int x0 = seg * SEG + threadIdx.x * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // every load of the strip first (thirty dwords in flight per thread), then the arithmetic, then the stores
+  MinRaw raw[MIN_RS + 2];
+#pragma unroll
+  for (int r = 0; r < MIN_RS + 2; ++r) raw[r] = minima_load<ALIGNED>(row_ptr(y0 + r - 1), W, x0);
+  MinRow above = minima_row<ALIGNED>(raw[0], W, x0), mid = minima_row<ALIGNED>(raw[1], W, x0);
+  uint32_t mine = 0;      // lane r ends up with the wave's count of row y0 + r
+  uint32_t nib[MIN_RS];
+#pragma unroll
+  for (int r = 0; r < MIN_RS; ++r) {
+    const MinRow below = minima_row<ALIGNED>(raw[r + 2], W, x0);
+    const uint32_t m = minima_nibble(above, mid, below);
+    nib[r] = m;
+    const uint32_t c = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((m & 1u) != 0u)) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((m & 2u) != 0u)) +
+                       (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((m & 4u) != 0u)) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((m & 8u) != 0u));      // (scalar: the wave's count)
+    if (lane == r) mine = c;
+    above = mid;
+    mid = below;
   }
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+#pragma unroll
+  for (int r = 0; r < MIN_RS; ++r)      // (a group beyond the row's end: 0)
+    if (y0 + r < H) nibbles[((size_t)(y0 + r) * segs + seg) * 256 + threadIdx.x] = (uint8_t)nib[r];
+  if (lane < MIN_RS) s_wave[wave * MIN_RS + lane] = mine;
   __syncthreads();
-  if (threadIdx.x == 0) counts[y] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  if (threadIdx.x < MIN_RS) {
+    const uint32_t c = y0 + (int)threadIdx.x < H ? s_wave[threadIdx.x] + s_wave[MIN_RS + threadIdx.x] + s_wave[2 * MIN_RS + threadIdx.x] + s_wave[3 * MIN_RS + threadIdx.x] : 0u;
+    if (c) atomicAdd(&counts[y0 + threadIdx.x], c);
+    uint32_t strip = c;      // (MIN_RS == 8 lanes: three steps)
+#pragma unroll
+    for (int off = MIN_RS / 2; off > 0; off >>= 1) strip += __shfl_down(strip, off, 64);
+    if (threadIdx.x == 0 && strip) atomicAdd(&counts[H + y0 / MIN_RS], strip);
+  }
 }
 
+// counts: minima_segments(h, w) words, zeroed here: [y] row y's count, [h + k] the count of rows 8k .. 8k+7 (minima_write
+// turns them into list positions itself: a scan launch of their own cost 8 us, a "last workgroup scans" counter that all
+// 8192 workgroups add to 330 -- atomics to ONE address run at ~25 M/s on this chip)
 hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h, int w, uint32_t *counts, uint8_t *nibbles) {
   if (h == 0 || w == 0) return hipSuccess;
-  k_minima_count<<<h, 256, 0, s>>>(img, stride, h, w, counts, nibbles);
+  hipError_t e = hipMemsetAsync(counts, 0, minima_segments(h, w) * sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  const int segs = (w + SEG - 1) / SEG;
+  const unsigned grid = (unsigned)(((h + MIN_RS - 1) / MIN_RS) * segs);
+  if (((reinterpret_cast<uintptr_t>(img) | stride) & 3u) == 0 && (w & 3) == 0 && w >= 4)
+    k_minima_count<true><<<grid, 256, 0, s>>>(img, stride, h, w, counts, nibbles);
+  else
+    k_minima_count<false><<<grid, 256, 0, s>>>(img, stride, h, w, counts, nibbles);
   return hipGetLastError();
 }
 
-// single-workgroup exclusive scan (n up to a few million entries); total -> *total
-__global__ __launch_bounds__(1024) void k_exclusive_scan(uint32_t *data, size_t n, uint32_t *total) {
-  __shared__ uint32_t s_part[1024];
-  const int t = threadIdx.x;
-  const size_t chunk = (n + 1023) / 1024;
-  const size_t b = (size_t)t * chunk, e = b + chunk < n ? b + chunk : n;
-  uint32_t sum = 0;
-  for (size_t i = b; i < e; ++i) sum += data[i];
-  s_part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
-    uint32_t v = t >= off ? s_part[t - off] : 0u;
-    __syncthreads();
-    s_part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = t ? s_part[t - 1] : 0u;
-  for (size_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
-  if (t == 1023) *total = s_part[1023];
-}
-
-hipError_t exclusive_scan_u32(hipStream_t s, uint32_t *data, size_t n, uint32_t *total) {
-  k_exclusive_scan<<<1, 1024, 0, s>>>(data, n, total);
-  return hipGetLastError();
-}
-
+// The write pass: one WAVE per row, no barrier.  A lane takes the nibbles of 32 consecutive pixels (8 bytes) per step, 64 such
+// groups a step; a wave scan of their counts gives every group its place in the list.
+// mask / word_base (optional, W % 32 == 0): the seed side tables of this very list (k_seed_tables builds them from a list
+// it has to search and check; here they fall out of the compaction: a group IS a mask word, its place in the list the
+// word's base).  With them the kernel also zeroes the two small arrays that k_seed_tables zeroes for the transform.
+// out_rc may then be null: a transform seeded by the image's own minima needs no list.
 __global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict__ nibbles, int H, int W,
-                                                      const uint32_t *__restrict__ offsets, uint32_t *out_rc, size_t cap) {
-  __shared__ uint32_t s_wave[4];
-  const int y = blockIdx.x, segs = (W + SEG - 1) / SEG;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  size_t row_pos = offsets[y];
-  for (int seg = 0; seg < segs; ++seg) {
-    const int x0 = seg * SEG + threadIdx.x * 4;
-    const uint32_t m = nibbles[((size_t)y * segs + seg) * 256 + threadIdx.x];
-    const uint32_t c = __popc(m);
-    // exclusive prefix of c inside the wave, then across the 4 waves
+                                                      const uint32_t *__restrict__ counts, uint32_t *out_rc, size_t cap,
+                                                      uint32_t *mask, uint32_t *word_base,
+                                                      uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b, uint32_t *total) {
+  __shared__ uint32_t s_part[4];
+  {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
+    for (size_t i = tid; i < n_zero_b; i += step) zero_b[i] = 0u;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, y0 = blockIdx.x * 4, y = y0 + wave;
+  // Where the workgroup's first row starts in the list: the strips before its own (counts[H + k]: at most H / 8 words,
+  // L2-resident, summed by all 256 threads), then the rows of its own strip before it.
+  const int strip0 = y0 / MIN_RS;
+  uint32_t part = 0;
+  for (int k = (int)threadIdx.x; k < strip0; k += 256) part += counts[H + k];
+  if ((int)threadIdx.x < y0 - strip0 * MIN_RS) part += counts[strip0 * MIN_RS + threadIdx.x];
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if (lane == 0) s_part[wave] = part;
+  __syncthreads();
+  if (y >= H) return;
+  size_t pos = (size_t)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  for (int k = 0; k < wave; ++k) pos += counts[y0 + k];
+  if (y == H - 1 && lane == 0) *total = (uint32_t)pos + counts[y];
+  const int segs = (W + SEG - 1) / SEG, groups = segs * 32;      // 8-byte groups of the row's nibble bytes
+  const uint2 *nb = reinterpret_cast<const uint2 *>(nibbles + (size_t)y * segs * 256);
+  for (int g0 = 0; g0 < groups; g0 += 64) {
+    const int g = g0 + lane;
+    const uint2 eight = g < groups ? nb[g] : make_uint2(0u, 0u);
+    // eight low nibbles -> one word: bit 4k + j = pixel 32 g + 4k + j
+    uint32_t lo = eight.x & 0x0F0F0F0Fu, hi = eight.y & 0x0F0F0F0Fu;
+    lo = (lo | (lo >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 4)) & 0x00FF00FFu;
+    lo = (lo | (lo >> 8)) & 0xFFFFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+    uint32_t word = lo | (hi << 16);
+    const uint32_t c = __popc(word);
     const uint32_t incl = wave_inclusive_sum(c);
-    __syncthreads();                               // s_wave of the previous step has been read
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { wave_base += k < wave ? s_wave[k] : 0u; total += s_wave[k]; }
-    size_t pos = row_pos + wave_base + (incl - c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if ((m >> k) & 1u) {
-        if (pos < cap) *reinterpret_cast<uint2 *>(out_rc + 2 * pos) = make_uint2((uint32_t)y, (uint32_t)(x0 + k));
-        ++pos;
+    size_t at = pos + incl - c;
+    if (mask && g < groups && g * 32 < W) {      // (W % 32 == 0: the word lies in this row, and in the plane)
+      const size_t wi = ((size_t)y * W >> 5) + g;
+      mask[wi] = word;
+      word_base[wi] = (uint32_t)at;
+    }
+    if (out_rc) {
+      while (word) {
+        const int b = __builtin_ctz(word);
+        word &= word - 1u;
+        if (at < cap) *reinterpret_cast<uint2 *>(out_rc + 2 * at) = make_uint2((uint32_t)y, (uint32_t)(g * 32 + b));
+        ++at;
       }
     }
-    row_pos += total;
+    pos += (uint32_t)__shfl((int)incl, 63, 64);
   }
 }
 
-hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *offsets, uint32_t *out_rc, size_t cap) {
-  if (h == 0 || w == 0) return hipSuccess;
-  k_minima_write<<<h, 256, 0, s>>>(nibbles, h, w, offsets, out_rc, cap);
+hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *counts, uint32_t *total, uint32_t *out_rc, size_t cap,
+                        uint32_t *mask, uint32_t *word_base, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
+  if (h == 0 || w == 0) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+  k_minima_write<<<(h + 3) / 4, 256, 0, s>>>(nibbles, h, w, counts, out_rc, cap, mask, word_base, zero_a, n_zero_a, zero_b, n_zero_b, total);
   return hipGetLastError();
 }
 

@@ -16,7 +16,11 @@ namespace wsapi {
 // stacked coordinates and slice_first (device) holds every slice's first list index, so that colours restart per slice.
 int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int pw, uint32_t max_level,
                    const uint32_t *d_seeds, size_t n_seeds, uint32_t *d_labels, bool tables, bool *mispredicted,
-                   int slice_h, const uint32_t *slice_first, bool padded) {
+                   int slice_h, const uint32_t *slice_first, bool padded, MinimaSeeds *minima) {
+  // minima: the seeds are the strict 8-neighbour maxima of d_img itself (what find_local_minima returns, in its order), and
+  // the TABLES come from the same three launches that would have written that list -- the count per row, the scan, the
+  // compaction -- instead of k_seed_tables' search through it: the README's call pair (lib.rs:73-86) without the 16-byte-
+  // per-seed list in between (8192^2: 117 MB that a host caller would also have carried over PCIe, both ways).
   // padded: edge correction -- d_img is the caller's (ph - 2) x (pw - 2) image (per slice), the ring of zeros around it is
   // virtual (padded_img_index, ws_common.hpp)
   const size_t n = (size_t)ph * pw;
@@ -27,6 +31,8 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   if ((rc = ensure(c, c->stamps, std::max(ntiles, relax_tiles(ph, pw)) * 4 * 2 * sizeof(uint32_t)))) return rc;
   if (tables && (rc = ensure(c, c->seed_tab, (nwords ? nwords : 1) * 2 * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(c, c->tile_list, relax_list_words(ph, pw) * sizeof(uint32_t)))) return rc;
+  if (minima && (rc = ensure(c, c->min_counts, std::max<size_t>(minima_segments(ph, pw), 1) * sizeof(uint32_t)))) return rc;
+  if (minima && (rc = ensure(c, c->min_nibbles, std::max<size_t>(minima_mask_bytes(ph, pw), 1)))) return rc;
   uint32_t *tile_list = (uint32_t *)c->tile_list.p;
   uint32_t *keys = (uint32_t *)c->keys.p;
   uint32_t *flags = (uint32_t *)c->flags.p;
@@ -49,6 +55,20 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   key.img = d_img; key.seeds = d_seeds; key.labels = d_labels; key.slice_first = slice_first; key.tile_min = c->tile_min_out;
   key.stride = stride; key.n_seeds = n_seeds; key.ph = ph; key.pw = pw; key.slice_h = slice_h; key.padded = padded; key.max_level = max_level;
   key.generation = c->buffer_generation;
+  key.from_minima = minima != nullptr;
+  if (minima) { key.seeds = minima->d_list; key.n_seeds = minima->cap; }
+  // the tables: from the list, or from the image
+  auto make_tables = [&]() -> hipError_t {
+    if (!minima)
+      return seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
+                         relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
+    uint32_t *counts = (uint32_t *)c->min_counts.p;
+    uint8_t *nibbles = (uint8_t *)c->min_nibbles.p;
+    hipError_t e = minima_count(c->stream, d_img, stride, ph, pw, counts, nibbles);
+    if (e == hipSuccess)
+      e = minima_write(c->stream, nibbles, ph, pw, counts, flags + FLAG_TOTAL, minima->d_list, minima->cap, seed_mask, word_base, stamps, relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC);
+    return e;
+  };
   const bool graph_ok = use_graph && c->stream != nullptr && !c->graph_unusable && tables && n != 0 && n < 0x80000000ull && !c->profiling && c->misc_clean &&
                         c->debug_max_iters == 0xFFFFFFFFu;
   const bool resume = c->async_phase == ws_ctx::ASYNC_RESUME;      // ws_segment_device_end: the graph of this very call is in flight
@@ -72,8 +92,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   if (graph_mode == 2) {
     const PassFlags gpf = make_pf(c);
     hipGraph_t graph = nullptr;
-    hipError_t e = seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
-                               relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw);
+    hipError_t e = make_tables();
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
       e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px, c->persistent_pass);
     const uint32_t last = GRAPH_PASSES - 1;
@@ -83,12 +102,12 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     // the read-backs: the lookahead pass's convergence slot and the error words
     if (e == hipSuccess && c->pinned_dev)
       e = words_to_host(c->stream, edge_slot(flags, last), FLAG_SLOT, c->pinned_dev + FLAG_EDGE + (last % COUNTER_RING) * FLAG_SLOT,
-                        flags + FLAG_OVERFLOW, FLAG_NERR, c->pinned_dev + FLAG_OVERFLOW);
+                        flags + FLAG_OVERFLOW, FLAG_NERR + 1, c->pinned_dev + FLAG_OVERFLOW);      // (+ 1: FLAG_TOTAL, the minima's count)
     if (e == hipSuccess && !c->pinned_dev)
       e = hipMemcpyAsync(&c->pinned[FLAG_EDGE + (last % COUNTER_RING) * FLAG_SLOT], edge_slot(flags, last), FLAG_SLOT * sizeof(uint32_t),
                          hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && !c->pinned_dev)
-      e = hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, FLAG_NERR * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      e = hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, (FLAG_NERR + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
     if (e == hipSuccess && e2 == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
@@ -125,8 +144,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     // The same launch clears the relaxation's tile-edge stamps and the striped flag words.  The
     // arrival-stamp plane is not touched: relaxation pass 0 derives it from the seeds.
     if (tables)
-      HIP_TRY(c, seed_tables(c->stream, d_seeds, n_seeds, ph, pw, seed_mask, word_base, flags + FLAG_SEED_ERR, stamps,
-                             relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC, slice_first, (size_t)slice_h * pw));
+      HIP_TRY(c, make_tables());
     else      // one pass over the label plane paints the seeds (colour i + 1, later duplicates win), zero elsewhere
       HIP_TRY(c, paint_labels(c->stream, d_seeds, n_seeds, ph, pw, d_labels, flags + FLAG_SEED_ERR, stamps,
                               relax_tiles(ph, pw) * 4 * 2, flags, FLAG_MISC));
@@ -191,7 +209,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   c->stats.launches_resolve = c->stats.resolve_passes;
   const bool all_read = graph_mode != 0 && converged_at == GRAPH_PASSES - 1;      // the graph's own read-backs cover everything
   if (!all_read)
-    HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, FLAG_NERR * sizeof(uint32_t),
+    HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, (FLAG_NERR + 1) * sizeof(uint32_t),
                               hipMemcpyDeviceToHost, c->stream));
   if (all_read) {
   } else if (c->profiling) {      // striped statistics: tiles that ran and in-tile sweeps, summed over passes
@@ -206,9 +224,10 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   } else {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  if (minima) minima->found = c->pinned[FLAG_TOTAL];
   if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
-  c->expect_sorted = c->pinned[FLAG_NONSTRICT] == 0;
-  if (tables && !c->expect_sorted) {      // the tables describe some other list: nothing computed from them counts
+  if (!minima) c->expect_sorted = c->pinned[FLAG_NONSTRICT] == 0;
+  if (tables && !minima && !c->expect_sorted) {      // the tables describe some other list: nothing computed from them counts
     *mispredicted = true;
     return WS_OK;
   }
@@ -391,6 +410,103 @@ int ws_segment_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_
   if (!c) return WS_ERR_BAD_ARG;
   if (c->async_phase != ws_ctx::ASYNC_NONE) return fail(c, WS_ERR_BAD_ARG, "a transform begun with ws_segment_device_begin has not been ended");
   return segment_device_body(c, d_img, h, w, stride, d_seeds_rc, n_seeds, opt, d_labels);
+}
+
+// ---- the README's call pair as one call (lib.rs:73-86): seeds = find_local_minima(img), labels = transform(img, seeds) -----------
+// Fast form: fused engine, no edge correction, w % 32 == 0 -- the seed side tables come straight out of the minima kernels
+// (run_fused_form, MinimaSeeds) and the list is only written when the caller wants it.  Anything else runs the two calls.
+static int segment_minima_device_body(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const ws_options *opt,
+                                      uint32_t *d_labels, uint32_t *d_seeds_out, size_t cap, size_t *n_found) {
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  if (!n_found || (!d_img && h * w) || (!d_labels && ph * pw) || (!d_seeds_out && cap)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  *n_found = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool fast = pick_engine(opt) == WS_ENGINE_FUSED && !opt->edge_correction && h >= 3 && w >= 3 && (w & 31) == 0 && h * w < 0x80000000ull;
+  if (fast) {
+    stats_begin(c);
+    MinimaSeeds ms{d_seeds_out, cap, 0};
+    bool mispredicted = false;
+    rc = run_fused_form(c, d_img, stride, (int)h, (int)w, opt->max_water_level, nullptr, 0, d_labels, true, &mispredicted, 0, nullptr, false, &ms);
+    if (rc) return rc;
+    *n_found = ms.found;
+    if ((rc = stats_end(c))) return rc;
+    // (an image without a single minimum: no seed, nothing is ever coloured -- the tables say so and the labels are zero)
+    return d_seeds_out && ms.found > cap ? fail(c, WS_ERR_CAPACITY, "seed buffer too small (the labels are complete)") : WS_OK;
+  }
+  // the two calls, through a list of the context's own when the caller's cannot hold it
+  const size_t bound = h >= 3 && w >= 3 ? ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) : 0;      // at most one strict maximum per 2 x 2 block
+  uint32_t *list = d_seeds_out;
+  size_t lcap = cap;
+  if (cap < bound) {
+    if ((rc = ensure(c, c->seed_stack, std::max<size_t>(bound, 1) * 2 * sizeof(uint32_t)))) return rc;
+    list = (uint32_t *)c->seed_stack.p;
+    lcap = bound;
+  }
+  size_t found = 0;
+  if ((rc = ws_find_local_minima_device(c, d_img, h, w, stride, list, lcap, &found))) return rc;
+  *n_found = found;
+  if ((rc = segment_device_body(c, d_img, h, w, stride, list, found, opt, d_labels))) return rc;
+  if (list != d_seeds_out && cap && found)
+    HIP_TRY(c, hipMemcpyAsync(d_seeds_out, list, std::min(found, cap) * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  if (list != d_seeds_out && cap) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return d_seeds_out && found > cap ? fail(c, WS_ERR_CAPACITY, "seed buffer too small (the labels are complete)") : WS_OK;
+}
+
+int ws_segment_minima_device(ws_ctx *c, const uint8_t *d_img, size_t h, size_t w, size_t stride, const ws_options *opt,
+                             uint32_t *d_labels, uint32_t *d_seeds_rc, size_t cap, size_t *n_seeds) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c) return WS_ERR_BAD_ARG;
+  return segment_minima_device_body(c, d_img, h, w, stride, opt, d_labels, d_seeds_rc, cap, n_seeds);
+}
+
+static int segment_minima_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const ws_options *opt,
+                               uint64_t *out64, uint32_t *out32, uint64_t *seeds_rc, size_t cap, size_t *n_seeds) {
+  if (!c) return WS_ERR_BAD_ARG;
+  if (!n_seeds || (!img && h * w) || (!seeds_rc && cap) || (!out64 && !out32)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = ph * pw;
+  if ((rc = ensure(c, c->img, std::max<size_t>(h * w, 1)))) return rc;
+  if ((rc = ensure(c, c->labels, std::max<size_t>(n, 1) * sizeof(uint32_t)))) return rc;
+  const size_t bound = h >= 3 && w >= 3 ? ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) : 0;
+  const size_t dcap = std::min(cap, bound);
+  if (dcap && (rc = ensure(c, c->seeds64, dcap * 2 * sizeof(uint32_t)))) return rc;
+  if (h * w) HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+  uint32_t *d_list = dcap ? (uint32_t *)c->seeds64.p : nullptr;
+  rc = segment_minima_device_body(c, (const uint8_t *)c->img.p, h, w, w, opt, (uint32_t *)c->labels.p, d_list, dcap, n_seeds);
+  const bool short_list = rc == WS_ERR_CAPACITY;
+  if (rc != WS_OK && !short_list) return rc;
+  const size_t got = std::min(*n_seeds, dcap);
+  if (got) {
+    if ((rc = ensure(c, c->out64, std::max<size_t>(std::max(got * 2, out64 ? n : 0), 1) * sizeof(uint64_t)))) return rc;
+    HIP_TRY(c, widen_pairs(c->stream, d_list, (uint64_t *)c->out64.p, got * 2));
+    HIP_TRY(c, hipMemcpyAsync(seeds_rc, c->out64.p, got * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (out64 && n) {
+    if ((rc = ensure(c, c->out64, n * sizeof(uint64_t)))) return rc;
+    HIP_TRY(c, widen_labels(c->stream, (const uint32_t *)c->labels.p, (uint64_t *)c->out64.p, n));
+    HIP_TRY(c, hipMemcpyAsync(out64, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (out32 && n) HIP_TRY(c, hipMemcpyAsync(out32, c->labels.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (seeds_rc && (short_list || *n_seeds > cap)) return fail(c, WS_ERR_CAPACITY, "seed buffer too small (the labels are complete)");
+  return WS_OK;
+}
+
+int ws_segment_minima(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const ws_options *opt, uint64_t *out_labels,
+                      uint64_t *seeds_rc, size_t cap, size_t *n_seeds) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  return segment_minima_host(c, img, h, w, stride, opt, out_labels, nullptr, seeds_rc, cap, n_seeds);
+}
+
+int ws_segment_minima_u32(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t stride, const ws_options *opt, uint32_t *out_labels,
+                          uint64_t *seeds_rc, size_t cap, size_t *n_seeds) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  return segment_minima_host(c, img, h, w, stride, opt, nullptr, out_labels, seeds_rc, cap, n_seeds);
 }
 
 // The two halves of ws_segment_device.  _begin queues the transform and returns; _end waits for it and reports its

@@ -58,6 +58,20 @@ class DeviceEngine:
                                                     out.data_ptr()))
         return out
 
+    def segment_minima(self, img, max_level=254, edge=False, engine=None, out=None, want_seeds=False):
+        """find_local_minima + segment as one call (ws_segment_minima_device): labels, n_seeds[, seeds]."""
+        assert img.dtype == torch.uint8 and img.dim() == 2 and img.is_contiguous() and img.is_cuda
+        h, w = img.shape
+        if out is None:
+            out = torch.empty(self._plane(img, edge), dtype=torch.int32, device=self.device)
+        opt = self.options(max_level, edge, engine, False)
+        cap = ((max(h, 1) - 1) // 2 + 1) * ((max(w, 1) - 1) // 2 + 1) if want_seeds else 0
+        seeds = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=self.device) if want_seeds else None
+        n = ctypes.c_size_t(0)
+        self.ctx.check(_ffi.lib().ws_segment_minima_device(self.ctx.handle, img.data_ptr(), h, w, w, ctypes.byref(opt), out.data_ptr(),
+                                                           seeds.data_ptr() if want_seeds else None, cap, ctypes.byref(n)))
+        return (out, n.value, seeds[: n.value]) if want_seeds else (out, n.value)
+
     def segment_begin(self, img, seeds, out, max_level=254, edge=False, seed_shift=False):
         """First half of segment() (ws_segment_device_begin): queues the transform and returns.  The engine is busy until
         segment_end(); img, seeds and out must stay alive and unchanged until then.  Two engines taking turns keep the

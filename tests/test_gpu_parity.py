@@ -279,6 +279,63 @@ def test_segment_u32_host_labels_equal_the_usize_plane(pkg):
         assert pkg._ffi.lib().ws_segment_u32(c.handle, img.ctypes.data, 300, 420, 420, seeds.ctypes.data, len(seeds), ctypes.byref(opt), None) == pkg._ffi.WS_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("shape,kind", [((96, 128), "noise"), ((257, 512), "noise"), ((300, 420), "noise"), ((130, 96), "smooth"), ((64, 1056), "smooth"),
+                                        ((3, 32), "noise"), ((2, 64), "noise"), ((40, 64), "flat")])
+@pytest.mark.parametrize("edge", [False, True])
+def test_transform_from_minima_is_the_call_pair(pkg, shape, kind, edge):
+    # ws_segment_minima: lib.rs:73-86's `find_local_minima` + `transform` as one call.  With w % 32 == 0 and no edge correction the
+    # seed tables come out of the minima kernels (no list); every other shape runs the two calls inside the library.
+    h, w = shape
+    img = cases.field(h, w, 31) if kind == "noise" else (cases.smooth_field(h, w, 9) if kind == "smooth" else np.full(shape, 17, dtype=np.uint8))
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    want = ol.segment(img, seeds, edge=edge) if h * w else None
+    ws = _seg(pkg, edge=edge)
+    got, got_seeds = ws.transform_from_minima(img, want_seeds=True)
+    assert got_seeds.shape == seeds.shape and (got_seeds == seeds).all()
+    assert got.dtype == np.uint64 and (got == want).all()
+    assert (ws.transform_from_minima(img) == want).all()                 # no list asked for: none is written
+    got32 = ws.transform_from_minima(img, labels_u32=True)
+    assert got32.dtype == np.uint32 and (got32 == want).all()
+    # a seed buffer that is too small: the labels are complete, the list is cut, the status says so
+    if len(seeds) > 1:
+        c, opt = ws._ctx(), ws._opt
+        e = 2 if edge else 0
+        out = np.zeros((h + e, w + e), dtype=np.uint64)
+        few = np.zeros((len(seeds) - 1, 2), dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        rc = pkg._ffi.lib().ws_segment_minima(c.handle, img.ctypes.data, h, w, w, ctypes.byref(opt), out.ctypes.data, few.ctypes.data, len(few), ctypes.byref(n))
+        assert rc == pkg._ffi.WS_ERR_CAPACITY and n.value == len(seeds)
+        assert (out == want).all() and (few == seeds[:-1]).all()
+
+
+def test_transform_from_minima_on_the_device_and_after_other_transforms(pkg):
+    # the device form, fast path (graph capture and replay on the third call), interleaved with list-seeded transforms of other planes
+    import torch
+    eng = _torch_engine(pkg)
+    himg = cases.field(512, 768, 77)
+    hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.uint64).reshape(-1, 2)
+    want = ol.segment_arrival(himg, hseeds)
+    img = torch.from_numpy(himg).to(eng.device)
+    out = torch.empty((512, 768), dtype=torch.int32, device=eng.device)
+    for k in range(4):
+        labels, n, seeds = eng.segment_minima(img, out=out, want_seeds=True)
+        assert n == len(hseeds) and (seeds.cpu().numpy().astype(np.uint64) == hseeds).all()
+        assert (labels.cpu().numpy().view(np.uint32) == want).all()
+        if k == 1:      # something else in between: the tables must be rebuilt, not remembered
+            other = cases.smooth_field(512, 768, 5)
+            os_ = np.asarray(ol.find_local_minima(other), dtype=np.int32).reshape(-1, 2)
+            got = eng.segment(torch.from_numpy(other).to(eng.device), torch.from_numpy(os_).to(eng.device))
+            assert (got.cpu().numpy().view(np.uint32) == ol.segment_arrival(other, os_.astype(np.uint64))).all()
+    labels, n = eng.segment_minima(img)
+    assert n == len(hseeds) and (labels.cpu().numpy().view(np.uint32) == want).all()
+    # a different image in the SAME buffer: a replayed graph reads the image again
+    himg2 = cases.smooth_field(512, 768, 12)
+    img.copy_(torch.from_numpy(himg2).to(eng.device))
+    labels, n = eng.segment_minima(img, out=out)
+    s2 = np.asarray(ol.find_local_minima(himg2), dtype=np.uint64).reshape(-1, 2)
+    assert n == len(s2) and (labels.cpu().numpy().view(np.uint32) == ol.segment_arrival(himg2, s2)).all()
+
+
 @pytest.mark.parametrize("size", [4096, 8192])
 def test_full_size_fixpoint_properties(pkg, size):
     # BASELINE.json headline size (8192^2) and the C4 slice size (4096^2): the oracle cannot run
