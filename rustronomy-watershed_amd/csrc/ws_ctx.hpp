@@ -72,7 +72,7 @@ struct ws_ctx {
   size_t block_h = 0, block_w = 0;
   size_t batch_max_px = 0x7FFFFFFFull;      // largest stack of slices run as one transform (ws_ctx_set_batch_pixel_limit)
   size_t seam_min_px = (size_t)1 << 24;     // smallest plane whose pass 1 is a seam repair (ws_ctx_set_seam_repair_min_pixels)
-  int persistent_pass = 0;                  // long-range floods: the first same-grid pass as a persistent tile-queue launch, 1 first come / 2 in flood order (ws_ctx_set_persistent_pass)
+  int persistent_pass = 3;                  // long-range floods: the first same-grid pass as a persistent tile-queue launch: 0 never, 1 first come, 2 in flood order, 3 auto (ws_ctx_set_persistent_pass)
   size_t live_list_min = (size_t)1 << 20;   // fewest colours for which merging lists are written from the live-lake list (ws_ctx_set_live_list_min_colours)
   // ws_segment_device_begin / _end: a transform whose replayed graph has been launched and whose host half (the wait, the
   // look at the convergence and error words, more passes if the flood needs them) is still to come

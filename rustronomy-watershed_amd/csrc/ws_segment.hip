@@ -42,6 +42,12 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   *mispredicted = false;
   c->graph_sufficed = false;
 
+  // The late passes of a long-range flood as one queue launch in flood order (relax_pass, ws_ctx_set_persistent_pass)?  Auto:
+  // when the seeds are sparse -- fewer than one per 64 of the 128 x 64 tiles, so every flood crosses many tiles -- and at
+  // least four (a single flood is a chain of tile runs either way, and a hop through the queue is no shorter than a pass).
+  // 8192^2 smooth maps: 35 seeds 6.9 -> 5.0 ms; 683 k and 8.6 k seeds (3.0 / 6.0 ms) and one seed (3.6 ms) stay with the passes.
+  const int persist_mode = c->persistent_pass != 3 ? c->persistent_pass
+                                                   : (!minima && n_seeds >= 4 && n_seeds * 64 <= relax_tiles(ph, pw) ? 2 : 0);
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
   // are free to change: a pipeline that reuses its buffers) replays its optimistic part -- seed tables, the first
@@ -94,7 +100,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
     hipGraph_t graph = nullptr;
     hipError_t e = make_tables();
     for (uint32_t pass = 0; pass < GRAPH_PASSES && e == hipSuccess; ++pass)
-      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px, c->persistent_pass);
+      e = relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, gpf, c->debug_max_iters, seed_mask, true, slice_h, true, padded, tile_list, c->seam_min_px, persist_mode);
     const uint32_t last = GRAPH_PASSES - 1;
     if (e == hipSuccess)
       e = resolve_two_launch(c->stream, keys, d_labels, ph, pw, (uint32_t *)c->refs.p, c->debug_max_iters, seed_mask, word_base,
@@ -174,7 +180,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   auto launch_pass = [&](uint32_t pass) {
     Span sp(c, KC_RELAX);
     return relax_pass(c->stream, d_img, stride, keys, ph, pw, max_level, pass, stamps, pf, c->debug_max_iters,
-                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list, c->seam_min_px, c->persistent_pass);
+                      tables ? seed_mask : d_labels, tables, slice_h, two_launch, padded, tile_list, c->seam_min_px, persist_mode);
   };
   if (graph_mode != 0) {
     // the graph ran seed tables, passes 0 .. GRAPH_PASSES - 1, the gated resolve and the read-backs

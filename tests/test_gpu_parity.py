@@ -419,11 +419,11 @@ def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, f
         seeds = seeds[::max(len(seeds) // 3, 1)]
     ws = _seg(pkg)
     c = ws._ctx()
-    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 3) == pkg._ffi.WS_ERR_BAD_ARG
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 4) == pkg._ffi.WS_ERR_BAD_ARG
     assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, mode) == 0
     got = ws.transform(img, seeds)
     st = c.stats()
-    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 3) == 0      # (the default: auto)
     assert st["relax_passes"] >= 9           # pass 7 was the queue, pass 8 looked at every tile again
     assert (got == ol.segment_arrival(img, seeds)).all()
     corridor = np.full((600, 1400), 255, dtype=np.uint8)      # one long winding corridor: a chain of tile runs, nothing in parallel
@@ -435,7 +435,7 @@ def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, f
     cs = np.array([[5, 4]], dtype=np.uint64)
     assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, mode) == 0
     got = ws.transform(corridor, cs)
-    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 0) == 0
+    assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 3) == 0
     assert (got == ol.segment_arrival(corridor, cs)).all()
 
 
