@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--merge", action="store_true")
+    ap.add_argument("--tolist", action="store_true", help="the merging transform_to_list (ws_transform_to_list_device), records left in HBM")
     args = ap.parse_args()
     ge.build_hip()
     ge.load_package()
@@ -38,8 +39,15 @@ def main():
     eng.segment(img, seeds, out=labels)
     keys_copy = eng.last_arrival()      # calibration: one 4N-byte device-to-device copy with 16 B/lane accesses
     torch.cuda.synchronize()
+    buf = None
+    if args.tolist:
+        _, off, _ = eng.transform_to_list(img, seeds)
+        buf = torch.empty((int(off[-1]) + 16, 2), dtype=torch.int64, device=eng.device)
+        torch.cuda.synchronize()
     for _ in range(args.steps):
-        if args.merge:
+        if args.tolist:
+            eng.transform_to_list(img, seeds, lakes=buf)
+        elif args.merge:
             eng.merge(img, seeds, out=labels)
         else:
             eng.segment(img, seeds, out=labels)
