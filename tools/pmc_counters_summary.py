@@ -21,7 +21,8 @@ def main():
             cnt[name][c].add((fi, row["Dispatch_Id"]))      # a counter may sit in several passes: every (pass, dispatch) is one sample
     out = {}
     for k in sorted(acc):
-        out[k] = {"launches": max(len(v) for v in cnt[k].values())}
+        # launches: dispatches of ONE pass (a counter that sits in several passes has one sample per pass and dispatch)
+        out[k] = {"launches": max(max(sum(1 for f, _ in v if f == fi) for fi in {f for f, _ in v}) for v in cnt[k].values())}
         for c in sorted(acc[k]):
             out[k][c] = acc[k][c] / max(len(cnt[k][c]), 1)
         d = out[k]
