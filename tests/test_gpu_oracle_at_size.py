@@ -54,6 +54,39 @@ def test_segmenting_equals_oracle_at_size(pkg, name):
     assert bad == 0, f"{name}: {bad} labels differ from the oracle"
 
 
+_SPARSE = []
+
+
+def _sparse_smooth_case():      # (one field, one oracle run for the three modes)
+    if not _SPARSE:
+        img = cases.smooth_field(4096, 4096, 21, octaves=8)
+        all_seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+        seeds = all_seeds[:: max(len(all_seeds) // 24, 1)][:30]
+        _SPARSE.append((img, seeds, ol.segment_arrival(img, seeds)))
+    return _SPARSE[0]
+
+
+@pytest.mark.parametrize("mode", [3, 2, 1])
+def test_sparse_seeds_on_a_smooth_map_take_the_tile_queue_and_equal_the_oracle(pkg, mode):
+    # Long-range floods: a smooth 4096^2 map with two dozen seeds.  Auto (3, the default) picks the persistent pass in flood
+    # order (seeds >= 4 and fewer than one per 64 tiles); 2 and 1 force the two queue forms.  Every label against the oracle.
+    import ctypes
+    import torch
+    img, seeds, want = _sparse_smooth_case()
+    assert 4 <= len(seeds) <= 33
+    eng = _engine()
+    L = importlib.import_module("rustronomy_watershed_amd._ffi").lib()
+    assert L.ws_ctx_set_persistent_pass(eng.ctx.handle, mode) == 0
+    eng.ctx.set_profiling(True)
+    got = _device_segment(eng, img, seeds)
+    st = eng.stats()
+    eng.ctx.set_profiling(False)
+    bad = int((got != want).sum())
+    assert bad == 0, f"mode {mode}: {bad} labels differ from the oracle"
+    # the queue launch stands for the scores of passes such a flood takes otherwise (pass 7 is the queue, then the check)
+    assert 9 <= st["relax_passes"] <= 40, st["relax_passes"]
+
+
 def test_headline_field_8192_equals_oracle(pkg):
     # the bench field itself (bench.py: generator seed 1, seeds = find_local_minima), every label against the oracle
     import torch
