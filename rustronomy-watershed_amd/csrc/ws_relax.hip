@@ -1411,6 +1411,16 @@ size_t relax_list_words(int h, int w) {
 #endif
 constexpr int RX_SNW = WS_SPLIT_NW;
 constexpr int RX_STW = RX_TW / 2, RX_STH = 2 * RX_SNW * RX_P;      // tile of the SPLIT kernel: 128 x 64
+// The queue in flood order runs on tiles of twice the height, 128 x 128 (sixteen waves): the launch is bound by the chain of
+// tile runs along the floods, and a flood crosses half as many of these vertically.  The ordinary same-grid passes are
+// slower on them (a pass lasts as long as its slowest tile); 8192^2 smooth maps, correlation 4 / 16 / 64 / 256 px, passes:
+// 3.06 / 6.04 / 6.94 / 3.73 ms on 128 x 64, 3.58 / 7.23 / 7.39 / 3.48 on 128 x 128; queue: 3.78 / 7.2 / 5.12 / 4.09 against
+// 3.69 / 6.75 / 4.69 / 3.65 (gpurun_out/r3am).
+#ifndef WS_QUEUE_NW
+#define WS_QUEUE_NW 16
+#endif
+constexpr int RX_QNW = WS_QUEUE_NW;
+constexpr int RX_QTH = 2 * RX_QNW * RX_P;
 size_t relax_tiles(int h, int w) {
   const int th = RX_NW * RX_P;
   const size_t a = (size_t)((w + RX_TW - 1) / RX_TW + 1) * ((h + th - 1) / th + 1);
@@ -1611,18 +1621,22 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
           if (e == hipSuccess && in_order)
             e = hipMemsetAsync(tile_list + pq_base(list_cap), 0, (PQ_HDR + (size_t)PQ_B * pq_words_per_bucket(list_cap)) * sizeof(uint32_t), s);
           if (e != hipSuccess) return e;
-          k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, in_order ? 2 : 1);
+          const int qy = (h + RX_QTH - 1) / RX_QTH;      // (flood order: the queue's own grid, 128 x 128)
+          if (in_order)
+            k_relax_list_regrid<RX_STW, RX_QTH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, qy, ax, ay, pass, prev, tile_list, list_cap, 2);
+          else
+            k_relax_list_regrid<RX_STW, RX_STH, RX_TW, RX_NW * RX_P><<<blocks, 256, 0, s>>>(h, w, gx, gy, ax, ay, pass, prev, tile_list, list_cap, 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
           // In flood order: one worker per CU.  Two (all that are resident) run twice as long each, the rounds too -- a
           // workgroup is one wave per SIMD, and two share their vector issue -- so nothing is gained where all are busy, and
           // where most are idle their looks at the counts are in the way: 8192^2 smooth maps, correlation 4 / 16 / 64 / 256 px,
           // 3.89 / 7.75 / 5.73 / 4.14 ms with 512 workers, 3.82 / 7.22 / 4.98 / 3.98 with 256 (gpurun_out/r3z).
           const unsigned workers = tuning_env("WS_RELAX_PERSIST_WORKERS") ? (unsigned)atoi(tuning_env("WS_RELAX_PERSIST_WORKERS"))
-                                                                          : std::min<unsigned>(in_order ? RX_LIST_GRID / 2 : RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * gy));
+                                                                          : std::min<unsigned>(in_order ? RX_LIST_GRID / 2 : RX_LIST_GRID * RX_NW / RX_SNW, (unsigned)(gx * (in_order ? qy : gy)));
           const uint32_t cap = tuning_env("WS_RELAX_PERSIST_CAP") ? (uint32_t)atoi(tuning_env("WS_RELAX_PERSIST_CAP")) : RLQ_ROUND_CAP;
           const int mode = tuning_env("WS_RELAX_PERSIST_MODE") ? atoi(tuning_env("WS_RELAX_PERSIST_MODE")) : 0;
           if (in_order)
-            k_relax<RX_SNW, true, true, true, true, 0, 2><<<workers, 64 * RX_SNW, 0, s>>>(img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, cap,
+            k_relax<RX_QNW, true, true, true, true, 0, 2><<<workers, 64 * RX_QNW, 0, s>>>(img, img_stride, keys, h, w, gx, qy, gx, qy, 0, chunk, max_level, pass, prev, cur, pf, cap,
                                                                                          nullptr, 0, sh, check_carry, pad, tile_list, mode, 1, 1, list_cap, 1);
           else
             k_relax<RX_SNW, true, true, true, true, 0, 1><<<workers, 64 * RX_SNW, 0, s>>>(img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, cap,
