@@ -343,14 +343,14 @@ __device__ __forceinline__ void scan_row(uint32_t (&t)[RX_P], const uint32_t (&b
 
 // The same idea down AND up the columns of a tile, in one phase: the rows of a column live in NB different bands (waves, or
 // halves of waves), so every band publishes its four rows of each column as two clamped increments in LDS -- entered from
-// above, entered from below -- and then composes the bands above it onto the tile's upper halo row and the bands below it
-// onto the lower one: NB - 1 LDS reads for every band, whichever it is, one barrier.  Then its own rows downwards from
-// what came from above, and upwards from what came from below.  Exact relaxation steps, like the row scan; what enters
-// from the other bands is their state when the phase began.
+// above, entered from below; two waves then walk the columns once -- down and up -- through those functions from the tile's
+// halo rows and leave every band the value that enters it; then every band takes its own rows downwards from what came
+// from above, and upwards from what came from below.  Exact relaxation steps, like the row scan; what enters from the other
+// bands is their state when the phase began.
 // (r2, first form: a scan down and a scan up, each with its own barriers and with 0 .. NB - 1 dependent reads depending
 // on the band -- the last band walked 15 bands while the others waited, twice per round: 4 of the 6.6 us of a tile run's
-// rounds, tools/diag_relax_smooth.hip.  tools/sim_tile_schedule.c, recipes "rdlu|L|" and "rlc|L|": same passes, tile
-// runs and rounds either way.)
+// rounds, tools/diag_relax_smooth.hip.  Second form: every band composed the NB - 1 others by itself, one barrier.
+// tools/sim_tile_schedule.c, recipes "rdlu|L|" and "rlc|L|": same passes, tile runs and rounds either way.)
 template <int NB, int TW, bool SPLIT>
 __device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uint32_t *fn, const uint32_t *halo_top, const uint32_t *halo_bottom,
                                                int band, int xl) {      // fn: [2][NB][2][TW]: direction, band, (lo, hi)
@@ -375,23 +375,33 @@ __device__ __forceinline__ void scan_cols_both(patch_t &T, const patch_t &B, uin
     }
   }
   __syncthreads();
-  const u32x4_t t4 = *reinterpret_cast<const u32x4_t *>(&halo_top[xl * RX_P]);
-  const u32x4_t b4 = *reinterpret_cast<const u32x4_t *>(&halo_bottom[xl * RX_P]);
-  uint32_t vd[RX_P] = {t4.x, t4.y, t4.z, t4.w}, vu[RX_P] = {b4.x, b4.y, b4.z, b4.w};
-  auto step = [&](uint32_t (&v)[RX_P], int dir, int k, bool mine) {
-    const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(slot(dir, k, 0));
-    const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(slot(dir, k, 1));
-    const uint32_t w0 = med3u(l4.x, v[0] + RX_P, g4.x), w1 = med3u(l4.y, v[1] + RX_P, g4.y);
-    const uint32_t w2 = med3u(l4.z, v[2] + RX_P, g4.z), w3 = med3u(l4.w, v[3] + RX_P, g4.w);
-    v[0] = mine ? w0 : v[0]; v[1] = mine ? w1 : v[1]; v[2] = mine ? w2 : v[2]; v[3] = mine ? w3 : v[3];
-  };
-  // SPLIT: a wave holds the bands 2w (lanes 0..31) and 2w + 1: the loops run over the bands that BOTH have before them,
-  // and the one band that only one half has before it takes a predicated step
-  const int lo_band = SPLIT ? band & ~1 : band, hi_band = SPLIT ? band | 1 : band;      // wave uniform
-  for (int k = 0; k < lo_band; ++k) step(vd, 0, k, true);
-  if (SPLIT) step(vd, 0, lo_band, band != lo_band);
-  for (int k = NB - 1; k > hi_band; --k) step(vu, 1, k, true);
-  if (SPLIT) step(vu, 1, hi_band, band != hi_band);
+  // What enters each band from above and from below is a chain through the bands' functions -- NB - 1 steps, but ONE chain
+  // per column and direction, not one per band: wave 0 walks down, wave 1 walks up, a lane per four columns, and leaves in
+  // the (lo) slot of every band the value that enters it.  (Every band composing the bands before it by itself: NB - 1 LDS
+  // reads of 32 bytes in every lane -- 1 MB per round and tile at sixteen waves, 3 of a round's 9 us.)
+  constexpr int LXc = TW / RX_P;      // lanes across a tile row
+  {
+    const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63);
+    if (w < 2 && l < LXc) {
+      const int dir = w;
+      const u32x4_t h4 = *reinterpret_cast<const u32x4_t *>(&(dir ? halo_bottom : halo_top)[l * RX_P]);
+      uint32_t v0 = h4.x, v1 = h4.y, v2 = h4.z, v3 = h4.w;
+#pragma unroll 4
+      for (int i = 0; i < NB; ++i) {
+        const int k = dir ? NB - 1 - i : i;
+        uint32_t *lo_p = fn + (((size_t)dir * NB + k) * 2 + 0) * TW + l * RX_P, *hi_p = lo_p + TW;
+        const u32x4_t l4 = *reinterpret_cast<const u32x4_t *>(lo_p);
+        const u32x4_t g4 = *reinterpret_cast<const u32x4_t *>(hi_p);
+        *reinterpret_cast<u32x4_t *>(lo_p) = u32x4_t{v0, v1, v2, v3};      // what enters band k
+        v0 = med3u(l4.x, v0 + RX_P, g4.x); v1 = med3u(l4.y, v1 + RX_P, g4.y);
+        v2 = med3u(l4.z, v2 + RX_P, g4.z); v3 = med3u(l4.w, v3 + RX_P, g4.w);
+      }
+    }
+  }
+  __syncthreads();
+  const u32x4_t d4 = *reinterpret_cast<const u32x4_t *>(slot(0, band, 0));
+  const u32x4_t u4 = *reinterpret_cast<const u32x4_t *>(slot(1, band, 0));
+  const uint32_t vd[RX_P] = {d4.x, d4.y, d4.z, d4.w}, vu[RX_P] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
   for (int c = 0; c < RX_P; ++c) {
     uint32_t n = vd[c];
