@@ -1488,11 +1488,26 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   // Passes from RX_SAME_GRID_FROM on all run on the anchored grid (relax_todo, read_same): in the long-range regime a tile
   // that stops at its round cap goes on itself, instead of handing its area to the FOUR tiles of the other grid that
   // cover it (each of which loads 8192 pixels to work on a quarter of them).
-  static const uint32_t same_from = [] {
+  static const uint32_t same_from_passes = [] {
     const char *e = tuning_env("WS_RELAX_SAME_GRID_FROM");      // tuning knob, tools/ only
     const uint32_t v = e ? (uint32_t)atoi(e) : RX_SAME_GRID_FROM;
     return v < 3u ? 3u : (v | 1u);                               // odd: the pass before it runs on the anchored grid
   }();
+  // The queue in flood order (persistent_pass == 2: the caller has seen sparse seeds, or was told to) starts as early as the
+  // schedule allows -- pass 3, right behind the seam repair and one pass with scans: a flood that crosses hundreds of tiles
+  // gains six of them from passes 3 .. 6 and pays six launches and their host round trip for it (8192^2, 35 seeds: 0.3 of
+  // 4.2 ms).  Pass 4 is then the pass that looks at every tile again; when it finds nothing to change the transform ends
+  // inside the replayed graph (run_fused_form: passes 0 .. 4 and the gated resolve).
+  static const uint32_t queue_from = [] {
+    const char *e = tuning_env("WS_RELAX_QUEUE_FROM");           // tuning knob, tools/ only
+    const uint32_t v = e ? (uint32_t)atoi(e) : 3u;
+    return v < 3u ? 3u : (v | 1u);
+  }();
+  const int persist_mode = tuning_env("WS_RELAX_PERSIST") ? atoi(tuning_env("WS_RELAX_PERSIST")) : persistent_pass;      // (A/B knob, tools/ only)
+  const bool queue_plane = persist_mode == 2 && tile_list && !pad && (w & 3) == 0 && w >= RX_P &&
+                           ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && relax_tiles(h, w) < (1u << 24);
+  const bool early_queue = queue_plane && queue_from < same_from_passes;
+  const uint32_t same_from = early_queue ? queue_from : same_from_passes;
   const int read_same = pass >= same_from ? 1 : 0, write_same = pass + 1 >= same_from ? 1 : 0;
   const uint32_t list_cap = (uint32_t)relax_tiles(h, w);      // entries per tile list
   const int shifted = read_same ? 0 : (int)(pass & 1u);
@@ -1525,7 +1540,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
     const char *e = tuning_env("WS_RELAX_SCAN_FROM");     // tuning knob, tools/ only
     return e ? (uint32_t)atoi(e) : RX_SCAN_FROM_PASS;
   }();
-  const uint32_t scan_from = std::max(scan_from_knob, 1u);
+  const uint32_t scan_from = early_queue ? same_from - 1u : std::max(scan_from_knob, 1u);
   if (pass >= scan_from && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
   // Passes 1 .. 3 have no scans: on a smooth map a tile that iterates to its own fixpoint by sweeps alone takes up to 64
   // rounds to carry a flood across its 256 columns, all 8192 tiles of them, in a pass that the scan passes then redo.
@@ -1591,10 +1606,11 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   } else {
     const int chunk = 4;
     const unsigned grid = (unsigned)((tx * ty + chunk - 1) / chunk);
-    static const uint32_t list_from = [] {
+    static const uint32_t list_from_passes = [] {
       const char *e = tuning_env("WS_RELAX_LIST_FROM");      // tuning knob, tools/ only
       return e ? (uint32_t)atoi(e) : RX_LIST_FROM_PASS;
     }();
+    const uint32_t list_from = early_queue ? same_from : list_from_passes;
     if (pass < scan_from) {
       k_relax<RX_NW, true, false, true><<<grid, 64 * RX_NW, 0, s>>>(img, img_stride, keys, h, w, tx, ty, ox_, oy_, shifted, chunk, max_level,
                                                               pass, prev, cur, pf, max_iters, nullptr, 0, sh, check_carry, pad, tile_list, 0, read_same, write_same, list_cap, 0);
@@ -1621,7 +1637,6 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         // 13-17 us either way (4 us of loads past L2, 4-8 of scan rounds, 3 of write-through stores, 2 of queue atomics), the
         // queue saves the launch gaps and the tails of the passes and pays for them with a sixth more tile runs (no pass
         // barrier: a tile runs on the first flag instead of on all flags of a pass) and with slower hops along a thin front.
-        const int persist_mode = tuning_env("WS_RELAX_PERSIST") ? atoi(tuning_env("WS_RELAX_PERSIST")) : persistent_pass;      // (A/B knob, tools/ only)
         const bool persist = persist_mode != 0 && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
                              ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap && list_cap < (1u << 24);
         if (persist) {
@@ -1652,7 +1667,9 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
             k_relax<RX_SNW, true, true, true, true, 0, 1><<<workers, 64 * RX_SNW, 0, s>>>(img, img_stride, keys, h, w, gx, gy, gx, gy, 0, chunk, max_level, pass, prev, cur, pf, cap,
                                                                                          nullptr, 0, sh, check_carry, pad, tile_list, mode, 1, 1, list_cap, 1);
           if ((e = hipGetLastError()) != hipSuccess) return e;
-          if (tuning_env("WS_RELAX_PERSIST_DIAG")) {      // tools/ only: what the workers did
+          hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+          (void)hipStreamIsCapturing(s, &capturing);
+          if (tuning_env("WS_RELAX_PERSIST_DIAG") && capturing == hipStreamCaptureStatusNone) {      // tools/ only: what the workers did
             uint32_t hd[RL_HDR];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(hd, tile_list, sizeof hd, hipMemcpyDeviceToHost);

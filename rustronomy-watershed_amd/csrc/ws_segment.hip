@@ -43,11 +43,10 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   c->graph_sufficed = false;
 
   // The late passes of a long-range flood as one queue launch in flood order (relax_pass, ws_ctx_set_persistent_pass)?  Auto:
-  // when the seeds are sparse -- fewer than one per 64 of the 128 x 64 tiles, so every flood crosses many tiles -- and at
-  // least four (a single flood is a chain of tile runs either way, and a hop through the queue is no shorter than a pass).
-  // 8192^2 smooth maps: 35 seeds 6.9 -> 5.0 ms; 683 k and 8.6 k seeds (3.0 / 6.0 ms) and one seed (3.6 ms) stay with the passes.
+  // when the seeds are sparse -- fewer than one per 64 of the 128 x 64 tiles, so every flood crosses many tiles.
+  // 8192^2 smooth maps: 35 seeds 6.9 -> 3.9 ms, one seed 3.6 -> 3.2 ms; 683 k and 8.6 k seeds (3.0 / 5.8 ms) stay with the passes.
   const int persist_mode = c->persistent_pass != 3 ? c->persistent_pass
-                                                   : (!minima && n_seeds >= 4 && n_seeds * 64 <= relax_tiles(ph, pw) ? 2 : 0);
+                                                   : (!minima && n_seeds >= 1 && n_seeds * 64 <= relax_tiles(ph, pw) ? 2 : 0);
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
   // are free to change: a pipeline that reuses its buffers) replays its optimistic part -- seed tables, the first

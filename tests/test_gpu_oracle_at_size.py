@@ -83,8 +83,9 @@ def test_sparse_seeds_on_a_smooth_map_take_the_tile_queue_and_equal_the_oracle(p
     eng.ctx.set_profiling(False)
     bad = int((got != want).sum())
     assert bad == 0, f"mode {mode}: {bad} labels differ from the oracle"
-    # the queue launch stands for the scores of passes such a flood takes otherwise (pass 7 is the queue, then the check)
-    assert 9 <= st["relax_passes"] <= 40, st["relax_passes"]
+    # the queue launch stands for the scores of passes such a flood takes otherwise (flood order: pass 3 is the queue, pass 4
+    # the check; first come: pass 7 and 8)
+    assert (5 if mode != 1 else 9) <= st["relax_passes"] <= 40, st["relax_passes"]
 
 
 def test_headline_field_8192_equals_oracle(pkg):

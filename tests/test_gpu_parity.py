@@ -424,7 +424,7 @@ def test_persistent_tile_queue_pass_gives_the_same_labels(pkg, shape, octaves, f
     got = ws.transform(img, seeds)
     st = c.stats()
     assert pkg._ffi.lib().ws_ctx_set_persistent_pass(c.handle, 3) == 0      # (the default: auto)
-    assert st["relax_passes"] >= 9           # pass 7 was the queue, pass 8 looked at every tile again
+    assert st["relax_passes"] >= (9 if mode == 1 else 5)      # first come: pass 7 was the queue, pass 8 looked at every tile again; flood order: passes 3 and 4
     assert (got == ol.segment_arrival(img, seeds)).all()
     corridor = np.full((600, 1400), 255, dtype=np.uint8)      # one long winding corridor: a chain of tile runs, nothing in parallel
     corridor[5:595:10, 3:-3] = 7
@@ -692,11 +692,16 @@ def test_long_range_passes_on_one_grid_odd_shapes(pkg, shape, octaves):
     img = cases.smooth_field(*shape, 23, octaves=octaves)
     allseeds = ol.find_local_minima(img)
     ws = _seg(pkg, pkg.ENGINE_FUSED)
+    set_mode = pkg._ffi.lib().ws_ctx_set_persistent_pass
     for seeds in (allseeds[:: max(len(allseeds) // 3, 1)][:3], allseeds):
-        got = ws.transform(img, seeds)
         want = ol.segment_arrival(img, seeds)
+        assert set_mode(ws._ctx().handle, 0) == 0      # the passes themselves (with sparse seeds the default would take the tile queue)
+        got = ws.transform(img, seeds)
+        assert set_mode(ws._ctx().handle, 3) == 0
         assert got.shape == want.shape and (got == want).all(), (shape, len(seeds))
         assert ws._ctx().stats()["relax_passes"] >= 8
+        got = ws.transform(img, seeds)                  # ... and whatever the default picks
+        assert (got == want).all(), (shape, len(seeds), "default")
     # the same through the merging transform (final labels) and with a low maximum level (large never-flooded regions)
     mg = pkg.TransformBuilder.new().set_max_water_lvl(120).build_merging()
     assert (mg.transform_final(img, allseeds) == ol.merge_arrival(img, allseeds, max_level=120)).all()
