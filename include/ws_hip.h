@@ -168,12 +168,12 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
  * over write-through / past L1 at agent scope); the pass after it looks at every tile again, so the labels are the same in
  * every mode.  1: first come, first served (a ring).  2: in flood order -- 31 buckets by the level of the smallest stamp that
  * waits at a tile's borders, the lowest non-empty bucket first, and a run that announces a tile of its own bucket takes it
- * itself.  0: the ordinary passes.  3 (the default): mode 2 when the seeds are sparse -- at least four, and fewer than one
- * per 64 tiles, so that every flood crosses many tiles -- the passes otherwise.  Measured on 8192^2 smooth maps of
- * correlation length 4 / 16 / 64 / 256 px (683 k / 8.6 k / 35 / 1 seeds): 3.0 / 6.0 / 6.9 / 3.6 ms with the passes,
- * 3.0 / 6.4 / 6.4 / 4.1 with mode 1, 3.8 / 7.2 / 5.0 / 4.0 with mode 2 (DESIGN.md section 10,
- * profiles/r3_v1_persistent_ab.txt): flood order pays where few floods cross the whole plane.  Transforms that converge in a
- * few passes (random fields) never reach that pass.  WS_ERR_BAD_ARG for any other mode. */
+ * itself; it runs on 128 x 128 tiles and starts at pass 3.  0: the ordinary passes.  3 (the default): mode 2 when the seeds
+ * are sparse -- fewer than one per 64 tiles, so that every flood crosses many tiles -- the passes otherwise.  Measured on
+ * 8192^2 smooth maps of correlation length 4 / 16 / 64 / 256 px (683 k / 8.6 k / 35 / 1 seeds): 3.0 / 5.8 / 6.7 / 3.5 ms with the
+ * passes, 3.0 / 6.4 / 6.4 / 4.1 with mode 1, 4.2 / 5.8 / 3.9 / 3.2 with mode 2, 3.0 / 5.8 / 3.9 / 3.2 with the default
+ * (profiles/r3_v1_persistent_ab.txt).  Transforms that converge in a few passes (random fields) never
+ * reach that pass.  WS_ERR_BAD_ARG for any other mode. */
 int ws_ctx_set_persistent_pass(ws_ctx *ctx, int mode);
 /* The merging transform_to_list of a seed list with at least this many entries writes every level's lake records from the
  * list of the lakes alive at the level before, instead of looking at every colour at every level (same records, the order
