@@ -721,6 +721,33 @@ def test_long_range_stacked_slices(pkg):
         assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
 
 
+def test_sparse_seeds_take_the_tile_queue_in_stacks_low_levels_and_merging(pkg):
+    # The default picks the persistent pass in flood order when seeds are sparse (fewer than one per 64 tiles).  Here: a stack
+    # of two smooth slices (slice walls inside the queue's 128 x 128 tiles), a low maximum level (few buckets: the queue's
+    # order has one or two levels per bucket, and most of the plane is never flooded), an odd-sized plane, the merging
+    # transform's final labels -- every label against the oracle.
+    import importlib
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    himgs = [cases.smooth_field(1024, 2048, 70 + k, octaves=7) for k in range(2)]
+    hseeds = [np.asarray(ol.find_local_minima(a), dtype=np.uint64).reshape(-1, 2) for a in himgs]
+    hseeds = [x[:: max(len(x) // 2, 1)][:2] for x in hseeds]
+    got = _run_batch(eng, himgs, hseeds)
+    assert eng.stats()["relax_passes"] <= 12      # (the queue stood for the passes)
+    for k in range(2):
+        assert (got[k] == ol.segment_arrival(himgs[k], hseeds[k])).all(), k
+    img = cases.smooth_field(1990, 2052, 33, octaves=7)
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    seeds = seeds[:: max(len(seeds) // 3, 1)][:3]
+    for max_level in (254, 90, 20):
+        ws = _seg(pkg, pkg.ENGINE_FUSED, max_level=max_level)
+        got = ws.transform(img, seeds)
+        assert (got == ol.segment_arrival(img, seeds, max_level=max_level)).all(), max_level
+        assert ws._ctx().stats()["relax_passes"] <= 12, max_level
+    mg = pkg.TransformBuilder.new().set_max_water_lvl(200).build_merging()
+    assert (mg.transform_final(img, seeds) == ol.merge_arrival(img, seeds, max_level=200)).all()
+
+
 def test_level_snapshots_on_the_device_match_transform_history(pkg):
     # ws_level_snapshot_device: the plane transform_history reports for a level, without leaving the device
     import torch
