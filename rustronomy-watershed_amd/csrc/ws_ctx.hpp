@@ -72,6 +72,7 @@ struct ws_ctx {
   size_t block_h = 0, block_w = 0;
   size_t batch_max_px = 0x7FFFFFFFull;      // largest stack of slices run as one transform (ws_ctx_set_batch_pixel_limit)
   size_t seam_min_px = (size_t)1 << 24;     // smallest plane whose pass 1 is a seam repair (ws_ctx_set_seam_repair_min_pixels)
+  size_t minima_found_before = 0;           // ws_segment_minima: how many seeds the previous such transform found (0: none yet)
   int persistent_pass = 3;                  // long-range floods: the first same-grid pass as a persistent tile-queue launch: 0 never, 1 first come, 2 in flood order, 3 auto (ws_ctx_set_persistent_pass)
   size_t live_list_min = (size_t)1 << 20;   // fewest colours for which merging lists are written from the live-lake list (ws_ctx_set_live_list_min_colours)
   // ws_segment_device_begin / _end: a transform whose replayed graph has been launched and whose host half (the wait, the
@@ -88,10 +89,11 @@ struct ws_ctx {
     size_t stride = 0, n_seeds = 0;
     int ph = 0, pw = 0, slice_h = 0;
     bool padded = false, from_minima = false;
+    int persist_mode = 0;      // the captured passes depend on it (relax_pass)
     uint32_t max_level = 0;
     uint64_t generation = 0;      // of the context's own buffers (buffer_generation)
     bool operator==(const GraphKey &o) const {
-      return generation == o.generation && from_minima == o.from_minima && img == o.img && seeds == o.seeds && labels == o.labels && slice_first == o.slice_first && tile_min == o.tile_min &&
+      return generation == o.generation && from_minima == o.from_minima && persist_mode == o.persist_mode && img == o.img && seeds == o.seeds && labels == o.labels && slice_first == o.slice_first && tile_min == o.tile_min &&
              stride == o.stride && n_seeds == o.n_seeds && ph == o.ph && pw == o.pw && slice_h == o.slice_h && padded == o.padded && max_level == o.max_level;
     }
   };

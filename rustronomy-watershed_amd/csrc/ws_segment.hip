@@ -45,8 +45,11 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   // The late passes of a long-range flood as one queue launch in flood order (relax_pass, ws_ctx_set_persistent_pass)?  Auto:
   // when the seeds are sparse -- fewer than one per 64 of the 128 x 64 tiles, so every flood crosses many tiles.
   // 8192^2 smooth maps: 35 seeds 6.9 -> 3.9 ms, one seed 3.6 -> 3.2 ms; 683 k and 8.6 k seeds (3.0 / 5.8 ms) stay with the passes.
+  // (seeds from the image's own minima: their number is only known afterwards -- the count of the context's previous such
+  // transform stands in for it, a prediction like expect_sorted; a wrong one costs time, not labels)
+  const size_t n_for_auto = minima ? c->minima_found_before : n_seeds;
   const int persist_mode = c->persistent_pass != 3 ? c->persistent_pass
-                                                   : (!minima && n_seeds >= 1 && n_seeds * 64 <= relax_tiles(ph, pw) ? 2 : 0);
+                                                   : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) / 64 ? 2 : 0);
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
   // are free to change: a pipeline that reuses its buffers) replays its optimistic part -- seed tables, the first
@@ -61,6 +64,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   key.stride = stride; key.n_seeds = n_seeds; key.ph = ph; key.pw = pw; key.slice_h = slice_h; key.padded = padded; key.max_level = max_level;
   key.generation = c->buffer_generation;
   key.from_minima = minima != nullptr;
+  key.persist_mode = persist_mode;
   if (minima) { key.seeds = minima->d_list; key.n_seeds = minima->cap; }
   // the tables: from the list, or from the image
   auto make_tables = [&]() -> hipError_t {
@@ -229,7 +233,7 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   } else {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  if (minima) minima->found = c->pinned[FLAG_TOTAL];
+  if (minima) { minima->found = c->pinned[FLAG_TOTAL]; c->minima_found_before = minima->found; }
   if (c->pinned[FLAG_SEED_ERR]) return fail(c, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
   if (!minima) c->expect_sorted = c->pinned[FLAG_NONSTRICT] == 0;
   if (tables && !minima && !c->expect_sorted) {      // the tables describe some other list: nothing computed from them counts

@@ -746,6 +746,28 @@ def test_sparse_seeds_take_the_tile_queue_in_stacks_low_levels_and_merging(pkg):
         assert ws._ctx().stats()["relax_passes"] <= 12, max_level
     mg = pkg.TransformBuilder.new().set_max_water_lvl(200).build_merging()
     assert (mg.transform_final(img, seeds) == ol.merge_arrival(img, seeds, max_level=200)).all()
+    # seeds = the image's own minima (ws_segment_minima): a map with a handful of them; the second call predicts "sparse" from
+    # the first one's count and takes the queue, the third replays the graph that holds it
+    import torch
+    few = np.full((2048, 2048), 200, dtype=np.uint8)
+    yy, xx = np.mgrid[0:2048, 0:2048]
+    for k, (cy, cx) in enumerate([(300, 400), (1500, 1700), (900, 1100), (1800, 200), (200, 1800)]):
+        d = np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+        few = np.minimum(few, np.clip(d / 6 + 3 * k, 0, 200)).astype(np.uint8)
+    few = (253 - few).astype(np.uint8)      # five peaks: find_local_minima returns strict maxima
+    for cy, cx in [(300, 400), (1500, 1700), (900, 1100), (1800, 200), (200, 1800)]:
+        few[cy, cx] += 1                    # (a strict one on top of each plateau)
+    fs = np.asarray(ol.find_local_minima(few), dtype=np.uint64).reshape(-1, 2)
+    assert 1 <= len(fs) <= 16
+    want = ol.segment_arrival(few, fs)
+    d_img = torch.from_numpy(few).to(eng.device)
+    out = torch.empty((2048, 2048), dtype=torch.int32, device=eng.device)
+    passes = []
+    for _ in range(3):
+        labels, n = eng.segment_minima(d_img, out=out)
+        assert n == len(fs) and (labels.cpu().numpy().view(np.uint32) == want).all()
+        passes.append(eng.stats()["relax_passes"])
+    assert passes[1] <= 12 and passes[2] <= 12, passes
 
 
 def test_level_snapshots_on_the_device_match_transform_history(pkg):
