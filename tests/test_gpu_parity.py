@@ -336,6 +336,21 @@ def test_transform_from_minima_on_the_device_and_after_other_transforms(pkg):
     assert n == len(s2) and (labels.cpu().numpy().view(np.uint32) == ol.segment_arrival(himg2, s2)).all()
 
 
+def test_transform_from_minima_at_the_headline_size_equals_the_two_calls(pkg):
+    # 8192^2 (BASELINE's field): ws_segment_minima_device against ws_find_local_minima_device + ws_segment_device, which
+    # test_headline_field_8192_equals_oracle compares with the oracle label by label
+    import torch
+    eng = _torch_engine(pkg)
+    img = eng.random_field(8192, 8192, 1)
+    seeds = eng.find_local_minima(img)
+    want = eng.segment(img, seeds).clone()
+    labels, n, got_seeds = eng.segment_minima(img, want_seeds=True)
+    assert n == seeds.shape[0] and bool((got_seeds == seeds).all())
+    assert bool((labels == want).all())
+    labels2, n2 = eng.segment_minima(img)      # (no list)
+    assert n2 == n and bool((labels2 == want).all())
+
+
 @pytest.mark.parametrize("size", [4096, 8192])
 def test_full_size_fixpoint_properties(pkg, size):
     # BASELINE.json headline size (8192^2) and the C4 slice size (4096^2): the oracle cannot run
