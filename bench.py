@@ -398,13 +398,19 @@ def run(args):
 
         # the batch goes through ws_segment_batch_group (csrc/ws_tiled.hip): this process drives ONE rank of the job (a local
         # group of one rank on its own device) -- independent slices need no exchange step, so no RCCL communicator is made
-        grp = wsg.Group.local(1, [dev_index])
+        # (`--local-ranks R`: the rank's slices as R stacks on R virtual ranks of the one device -- R transforms in flight)
+        vr = max(min(args.local_ranks, len(mine)), 1)
+        grp = wsg.Group.local(vr, [dev_index] * vr)
+        parts = []
+        for r in range(vr):
+            j0, j1 = len(mine) * r // vr, len(mine) * (r + 1) // vr
+            parts.append((cube[j0:j1], seeds[offs[j0]:offs[j1]].contiguous(), [o - offs[j0] for o in offs[j0:j1 + 1]], labels[j0:j1]))
 
         def step():
             if mine:
-                grp.segment_batch(H, W, [(cube, seeds, offs, labels)])
+                grp.segment_batch(H, W, parts)
         workload = (f"batch of {args.slices} independent {H}x{W} u8 random slices (CGPS-like cube), segmenting, slice i on rank "
-                    f"i % {world}; a rank's {len(mine)} slices run as one stacked transform (ws_segment_batch_group -> ws_segment_batch_device)")
+                    f"i % {world}; a rank's {len(mine)} slices run as {'one stacked transform' if vr == 1 else f'{vr} stacked transforms in flight on {vr} virtual ranks of its device'} (ws_segment_batch_group -> ws_segment_batch_device)")
         parallelism = f"independent slices, {len(mine)} per GPU x{world}, no data-path collective"
         units = {"slices_total": args.slices, "slices_per_gpu": len(mine)}
     else:   # c5
