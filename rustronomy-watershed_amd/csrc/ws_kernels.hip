@@ -1129,10 +1129,34 @@ __global__ __launch_bounds__(NTHREADS, 5) void k_resolve_local(const uint32_t *_
 // (groups of 8 regions balance badly on smooth maps, where every pixel is a reference and a region holds 1024: 8192^2 at
 // correlation 64 / 256 px 344 / 212 us against 301 / 144 with 4 and 269 / 259 for the old one-region walk; bench field 38 us either way)
 constexpr int CH_R = 4, CH_U = 4;
+
+// Follows the chain that starts with the reference `v` (the label some pixel holds) to its colour -- or to the first
+// reference that leads out of [follow_from, follow_from + span).  COMPRESS (planes whose chains cross many tiles: smooth
+// maps): a chain of more than two hops that ended in a colour is walked a second time and every pixel on it is given that
+// colour -- its own final label, so a plain store that no owner's store can contradict -- and whoever comes by later stops
+// there.  (Path halving by compare-and-swap was measured first: the chains are shared by thousands of waves, the swaps hit
+// the same addresses, and same-address atomics retire at ~25 M/s: the chase took twice as long, 0.43 -> 0.77 ms.)
+template <bool COMPRESS>
+__device__ __forceinline__ uint32_t follow_chain(uint32_t *labels, uint32_t v, size_t follow_from, size_t span, size_t n) {
+  const uint32_t start = v;
+  size_t hops = 1;
+  for (; (v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < span && hops < n; ++hops)
+    v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (COMPRESS && hops > 3 && !(v & REF_BIT)) {
+    uint32_t w = start;
+    for (size_t k = 1; k < hops && (w & REF_BIT) && (size_t)(w & ~REF_BIT) - follow_from < span; ++k) {
+      const uint32_t q = w & ~REF_BIT;
+      w = __hip_atomic_load(labels + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w & REF_BIT) __hip_atomic_store(labels + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const uint32_t *__restrict__ ref_count,
                                 const uint32_t *__restrict__ ref_list, size_t nregions, size_t n,
                                 const uint32_t *__restrict__ gate, const uint32_t *__restrict__ seed_err,
-                                size_t follow_from, size_t follow_to, int H, int W, int tilesX, uint32_t ntiles) {
+                                size_t follow_from, size_t follow_to, int H, int W, int tilesX, uint32_t ntiles, int halve) {
   // [follow_from, follow_to): the pixels a chain may be followed THROUGH -- the whole plane [0, n), or, for a row block
   // whose halo rows still hold references to themselves, the plane without those rows: a chain stops at a halo pixel.
   const int lane = threadIdx.x & 63;
@@ -1182,11 +1206,7 @@ __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const u
       }
 #pragma unroll
       for (int u = 0; u < CH_U; ++u) {
-        if (follow[u]) {
-          v[u] = first[u];
-          for (size_t hops = 1; (v[u] & REF_BIT) && (size_t)(v[u] & ~REF_BIT) - follow_from < span && hops < n; ++hops)
-            v[u] = __hip_atomic_load(labels + (v[u] & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (follow[u]) v[u] = follow_chain<false>(labels, first[u], follow_from, span, n);      // (lists: short chains, a hop or two)
       }
 #pragma unroll
       for (int u = 0; u < CH_U; ++u)
@@ -1238,8 +1258,7 @@ __global__ __launch_bounds__(256) void k_resolve_chase(uint32_t *labels, const u
               if (v == memo_from) v = memo_to;
               else {
                 const uint32_t from = v;
-                for (size_t hops = 1; (v & REF_BIT) && (size_t)(v & ~REF_BIT) - follow_from < span && hops < n; ++hops)
-                  v = __hip_atomic_load(labels + (v & ~REF_BIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = halve ? follow_chain<true>(labels, v, follow_from, span, n) : follow_chain<false>(labels, v, follow_from, span, n);
                 memo_from = from; memo_to = v;
               }
             }
@@ -1290,7 +1309,7 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
   const size_t from = (halo_flags & 1) ? (size_t)w : 0, to = (halo_flags & 2) ? n - (size_t)w : n;
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to, h, w, tx, (uint32_t)(tx * ty));
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to, h, w, tx, (uint32_t)(tx * ty), halo_flags == 0 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -1301,7 +1320,7 @@ hipError_t resolve_chase_again(hipStream_t s, uint32_t *labels, int h, int w, ui
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tiles_of(w) * tiles_of(h) * (NTHREADS / 64);
   const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n, h, w, tiles_of(w), (uint32_t)(tiles_of(w) * tiles_of(h)));
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_scratch, ref_scratch + nregions, nregions, n, nullptr, nullptr, 0, n, h, w, tiles_of(w), (uint32_t)(tiles_of(w) * tiles_of(h)), 0);
   return hipGetLastError();
 }
 
