@@ -371,6 +371,29 @@ impl<T> Watershed<T> for SegmentingWatershed<T> {
     }
 }
 
+impl<T> SegmentingWatershed<T> {
+    /// Not in the reference: its README's call pair (lib.rs:73-86), `transform(input, &find_local_minima(input))`, as ONE
+    /// call of the library (`ws_segment_minima`): the seeds never cross PCIe as (usize, usize) pairs unless asked for.
+    /// Returns the labels and, with `want_seeds`, the seed list the labels are numbered by (colour i + 1 = entry i).
+    pub fn transform_from_minima(&self, input: nd::ArrayView2<u8>, want_seeds: bool) -> (nd::Array2<usize>, Vec<(usize, usize)>) {
+        let (h, w) = input.dim();
+        let (std_img, stride) = shim::standard(&input);
+        let o = self.opt.ffi();
+        let mut out = nd::Array2::<usize>::zeros(self.opt.plane(h, w));
+        // at most one strict maximum per 2 x 2 block of the interior
+        let cap = if want_seeds && h >= 3 && w >= 3 { ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) } else { 0 };
+        let mut packed = vec![0u64; 2 * cap];
+        let mut n = 0usize;
+        shim::with_ctx(|ctx| unsafe {
+            let rc = hip_ffi::ws_segment_minima(ctx, std_img.as_ptr(), h, w, stride, &o, out.as_mut_ptr() as *mut u64,
+                                                if cap != 0 { packed.as_mut_ptr() } else { std::ptr::null_mut() }, cap, &mut n);
+            shim::check(ctx, rc, "ws_segment_minima");
+        });
+        let seeds = if want_seeds { packed.chunks_exact(2).take(n).map(|p| (p[0] as usize, p[1] as usize)).collect() } else { Vec::new() };
+        (out, seeds)
+    }
+}
+
 impl<T> Watershed<T> for MergingWatershed<T> {
     /// lib.rs:1524-1536: a stub in the reference (zeros, interior 123, seeds ignored); kept for drop-in fidelity.
     fn transform(&self, input: nd::ArrayView2<u8>, _seeds: &[(usize, usize)]) -> nd::Array2<usize> {
