@@ -243,6 +243,22 @@ class SegmentingWatershed : public Watershed<T> {     // lib.rs:1609-1849
     this->template run<int>(input, seeds, nullptr, &out);
     return out;
   }
+  // Not in the reference: its README's call pair, transform(input, find_local_minima(input)) (lib.rs:73-86), as ONE call of the
+  // library (ws_segment_minima).  `seeds_out` (optional) receives the list the labels are numbered by.
+  Array2<usize> transform_from_minima(ArrayView2<std::uint8_t> input, std::vector<Seed> *seeds_out = nullptr) const {
+    const std::size_t e = this->opt_.edge_correction ? 2 : 0;
+    Array2<usize> out(input.rows + e, input.cols + e);
+    const std::size_t cap = seeds_out && input.rows >= 3 && input.cols >= 3 ? ((input.rows - 1) / 2 + 1) * ((input.cols - 1) / 2 + 1) : 0;
+    std::vector<std::uint64_t> rc(2 * cap + 2);
+    std::size_t n = 0;
+    this->ctx_->check(ws_segment_minima(this->ctx_->get(), input.ptr, input.rows, input.cols, input.row_stride, &this->opt_,
+                                        reinterpret_cast<std::uint64_t *>(out.data.data()), cap ? rc.data() : nullptr, cap, &n));
+    if (seeds_out) {
+      seeds_out->resize(n);
+      for (std::size_t i = 0; i < n; ++i) (*seeds_out)[i] = {(usize)rc[2 * i], (usize)rc[2 * i + 1]};
+    }
+    return out;
+  }
 
  private:
   template <class U> friend class TransformBuilder;

@@ -65,6 +65,12 @@ static int gpu_checks() {
                       nullptr, nullptr, nullptr) == 0);
   CHECK(out.rows == H && out.cols == W);
   CHECK(std::memcmp(out.data.data(), want.data(), H * W * 8) == 0);
+  // the call pair as one call (ws_segment_minima): same labels, same list
+  std::vector<ws::Seed> mins2;
+  auto out2 = watershed.transform_from_minima(rf, &mins2);
+  CHECK(mins2 == mins);
+  CHECK(std::memcmp(out2.data.data(), want.data(), H * W * 8) == 0);
+  CHECK(std::memcmp(watershed.transform_from_minima(rf).data.data(), want.data(), H * W * 8) == 0);
 
   // hook: count coloured pixels per level (HookCtx, lib.rs:844-862) vs the oracle's hook
   struct Acc { std::vector<size_t> v; } acc;
