@@ -124,7 +124,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
                       bool padded = false,                      // edge correction: img is the caller's (h-2) x (w-2) image, the ring of zeros is virtual
                       uint32_t *tile_list = nullptr,            // relax_list_words(h, w) words: late passes run from a compacted list of tiles
                       size_t seam_min_px = (size_t)1 << 24,     // planes from this many pixels on repair pass 0's seams with bands and strips (ws_relax.hip)
-                      int persistent_pass = 0);                 // the first same-grid pass of a long-range flood as one persistent launch with a tile queue: 1 first come, 2 in flood order (opt-in)
+                      int persistent_pass = 0);                 // the late passes of a long-range flood as one persistent launch with a tile queue: 1 first come (from pass 7), 2 in flood order (from pass 3); the caller resolves "auto"
 size_t relax_list_words(int h, int w);
 bool relax_uses_seam_repair(int h, int w, bool seed_bits, int slice_h, bool padded, size_t seam_min_px);      // pass 1 of such a transform is two launches
 

@@ -1632,11 +1632,13 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         // The first same-grid pass as ONE persistent launch (k_relax, PERSIST): workgroups pull tiles from a queue and a tile
         // that changes something its neighbour must see queues that neighbour at once.  The pass after it runs every tile
         // from an all-tiles list, so the fixpoint is certified by the ordinary machinery whatever the queue did.
-        // Opt-in (ws_ctx_set_persistent_pass): 8192^2 smooth maps, correlation length 4 / 16 / 64 / 256 px: 3.07 / 6.05 / 7.03 / 3.65 ms
-        // with the passes, 3.01 / 6.36 / 6.36 / 4.05 ms with the queue (profiles/r3_v1_persistent_ab.txt) -- a tile run costs
-        // 13-17 us either way (4 us of loads past L2, 4-8 of scan rounds, 3 of write-through stores, 2 of queue atomics), the
-        // queue saves the launch gaps and the tails of the passes and pays for them with a sixth more tile runs (no pass
-        // barrier: a tile runs on the first flag instead of on all flags of a pass) and with slower hops along a thin front.
+        // 8192^2 smooth maps, correlation length 4 / 16 / 64 / 256 px (profiles/r3_v1_persistent_ab.txt): 3.0 / 5.8 / 6.7 / 3.5 ms
+        // with the passes; first come (mode 1) 3.0 / 6.4 / 6.4 / 4.1 -- a tile run costs 13-17 us either way (4 us of loads past
+        // L2, 4-8 of scan rounds, 3 of write-through stores, 2 of queue atomics), the queue saves the launch gaps and the
+        // tails of the passes and pays for them with a sixth more tile runs (a tile runs on the first flag instead of on all
+        // flags of a pass); in flood order (mode 2, from pass 3, on 128 x 128 tiles) 4.2 / 5.8 / 3.9 / 3.0: a third of the
+        // tile runs, and a win where floods are long.  The context picks mode 2 by itself when seeds are sparse
+        // (run_fused_form); ws_ctx_set_persistent_pass forces or forbids.
         const bool persist = persist_mode != 0 && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
                              ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap && list_cap < (1u << 24);
         if (persist) {
