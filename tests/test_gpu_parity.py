@@ -872,6 +872,38 @@ def test_segment_begin_end_pipelined_on_two_contexts(pkg):
         _pipelined_begin_end(pkg, dev, torch, mode)
 
 
+def test_segment_begin_end_with_the_tile_queue_inside_the_graph(pkg):
+    # sparse seeds on smooth maps: the replayed graph of _begin then holds the tile queue (pass 3), the check (pass 4) and the
+    # gated resolve; two contexts on two streams, their queue launches overlap on the GPU
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    engines = []
+    for s in (torch.cuda.Stream(0), torch.cuda.Stream(0)):
+        with torch.cuda.stream(s):
+            engines.append(dev.DeviceEngine(0))
+    dv = engines[0].device
+    ss, sw, sl = [], [], []
+    for k in range(2):
+        h = cases.smooth_field(1536, 2048, 80 + k, octaves=7)
+        s = np.asarray(ol.find_local_minima(h), dtype=np.uint64).reshape(-1, 2)
+        s = s[:: max(len(s) // 3, 1)][:3]
+        ss.append((torch.from_numpy(h).to(dv), torch.from_numpy(s.astype(np.int64).astype(np.int32)).to(dv).contiguous()))
+        sw.append(ol.segment_arrival(h, s))
+        sl.append(torch.zeros((1536, 2048), dtype=torch.int32, device=dv))
+    torch.cuda.synchronize()
+    for rnd in range(4):
+        for k, eng in enumerate(engines):
+            eng.segment_begin(ss[k][0], ss[k][1], sl[k])
+        for k, eng in enumerate(engines):
+            eng.segment_end()
+            assert (sl[k].cpu().numpy().view(np.uint32) == sw[k]).all(), (rnd, k)
+            sl[k].zero_()
+        torch.cuda.synchronize()
+    st = engines[0].stats()
+    assert st["graph_launches"] == 1 and st["relax_passes"] <= 12, st
+
+
 def _pipelined_begin_end(pkg, dev, torch, mode):
     # "events": two streams, the next transform waits for the other context's by an event; "one_stream": stream order does
     # it, and _end must wait for its own graph only (the other context's transform is queued behind it); "concurrent": two
