@@ -442,6 +442,25 @@ int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seed
                             const ws_options *opt /* edge_correction must be 0: pad the field first */, int merging,
                             uint32_t *exchange_rounds);
 
+/* The field cut in BOTH directions (BASELINE config 5's "2-D tiles"): py x px tiles, rank = ty * px + tx, py * px = the
+ * group's ranks.  ws_tile_grid: rows[4] = {r0, r1, lo, hi} and cols[4] = {c0, c1, clo, chi} of a rank's tile -- owned
+ * [r0, r1) x [c0, c1), held [lo, hi) x [clo, chi) with a halo row / column on every side that has a neighbour (ws_tile_rows
+ * in each direction).  One descriptor per LOCAL rank; seeds carry their colours (index in the caller's list + 1,
+ * lib.rs:1670-1672: a tile's seeds are no contiguous range of the list).  The exchange is halo rows AND columns, 2 (w + h)
+ * words a tile and round; the block steps are the general form's (painted seeds, relaxation rounds, label rounds: the
+ * seed-table / boundary-table shortcuts of the row-block form are not built for tiles).  Segmenting transform only. */
+typedef struct ws_tile_block2d {
+  const uint8_t *d_img;        /* the tile's plane [lo, hi) x [clo, chi) of the field, on the rank's device */
+  size_t img_stride;           /* >= chi - clo (a view into the whole field works) */
+  const uint32_t *d_seeds_rc;  /* seeds on ANY pixel of the plane, halo ring included, LOCAL coordinates (row - lo, col - clo) */
+  const uint32_t *d_colours;   /* their colours */
+  size_t n_seeds;
+  uint32_t *d_labels;          /* out: (hi - lo) x (chi - clo) u32 */
+} ws_tile_block2d;
+int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows /* 4 */, size_t *cols /* 4 */);
+int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d *blocks,
+                              const ws_options *opt, uint32_t *exchange_rounds);
+
 /* BASELINE config C4 over a group: a batch of independent slices, slice i on rank i % world, a rank's slices as ONE stacked
  * transform (ws_segment_batch_device) -- no exchange step at all.  One descriptor per LOCAL rank: the rank's own slices,
  * contiguous in its HBM.  Local groups run their ranks side by side (a host thread each). */

@@ -70,6 +70,18 @@ pub struct ws_tile_block {
     pub d_labels: *mut u32,
 }
 
+/// One rank's tile of a field cut in both directions, device resident (ws_segment_tiled2d_device).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ws_tile_block2d {
+    pub d_img: *const u8,
+    pub img_stride: usize,
+    pub d_seeds_rc: *const u32,
+    pub d_colours: *const u32,
+    pub n_seeds: usize,
+    pub d_labels: *mut u32,
+}
+
 /// One rank's slices of a batch, device resident (ws_segment_batch_group); seed_offsets lives on the host.
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -227,6 +239,9 @@ extern "C" {
         n_seeds: usize, opt: *const ws_options, merging: c_int, out_labels: *mut u64, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block,
         opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_tile_grid(h: usize, w: usize, rank: c_int, py: c_int, px: c_int, rows: *mut usize, cols: *mut usize) -> c_int;
+    pub fn ws_segment_tiled2d_device(g: *mut ws_group, field_h: usize, field_w: usize, py: c_int, px: c_int,
+        blocks: *const ws_tile_block2d, opt: *const ws_options, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_batch_group(g: *mut ws_group, h: usize, w: usize, parts: *const ws_batch_part, opt: *const ws_options,
         failed_rank: *mut usize, failed_slice: *mut usize) -> c_int;
 }

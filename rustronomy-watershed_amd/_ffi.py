@@ -73,6 +73,11 @@ class TileBlock(ctypes.Structure):
                 ("first_colour", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("d_labels", vp)]
 
 
+class TileBlock2D(ctypes.Structure):
+    """ws_tile_block2d: one rank's tile of a field cut in both directions, device resident."""
+    _fields_ = [("d_img", vp), ("img_stride", sz), ("d_seeds_rc", vp), ("d_colours", vp), ("n_seeds", sz), ("d_labels", vp)]
+
+
 class BatchPart(ctypes.Structure):
     """ws_batch_part: one rank's slices of a batch, device resident (seed_offsets on the host)."""
     _fields_ = [("d_cube", vp), ("d_seeds_rc", vp), ("seed_offsets", szp), ("n_slices", sz), ("d_labels", vp)]
@@ -147,6 +152,8 @@ SIGNATURES = {
     "ws_tile_rows": (ctypes.c_int, [sz, ctypes.c_int, ctypes.c_int, szp, szp, szp, szp]),
     "ws_segment_tiled": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, vp, u32p]),
     "ws_segment_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, ctypes.POINTER(TileBlock), ctypes.POINTER(Options), ctypes.c_int, u32p]),
+    "ws_tile_grid": (ctypes.c_int, [sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, szp, szp]),
+    "ws_segment_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(TileBlock2D), ctypes.POINTER(Options), u32p]),
     "ws_segment_batch_group": (ctypes.c_int, [vp, sz, sz, ctypes.POINTER(BatchPart), ctypes.POINTER(Options), szp, szp]),
 }
 

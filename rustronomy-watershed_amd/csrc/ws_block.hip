@@ -74,6 +74,31 @@ hipError_t block_rows_differ(hipStream_t s, const uint32_t *a, const uint32_t *b
   return hipGetLastError();
 }
 
+// A block of a field cut in BOTH directions (ws_segment_tiled2d_device) has halo columns as well: column xl and column xr of
+// a plane of pitch w as two contiguous runs of h words (what a neighbour wants), and such runs back into columns 0 / w - 1.
+__global__ void k_pack_cols(const uint32_t *__restrict__ plane, size_t h, size_t w, size_t xl, size_t xr, uint32_t *out) {
+  const size_t y = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= h) return;
+  out[y] = plane[y * w + xl];
+  out[h + y] = plane[y * w + xr];
+}
+__global__ void k_unpack_cols(uint32_t *plane, size_t h, size_t w, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right) {
+  const size_t y = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= h) return;
+  if (left) plane[y * w] = left[y];
+  if (right) plane[y * w + w - 1] = right[y];
+}
+hipError_t block_pack_cols(hipStream_t s, const uint32_t *plane, size_t h, size_t w, size_t xl, size_t xr, uint32_t *out) {
+  if (h == 0 || w == 0) return hipSuccess;
+  k_pack_cols<<<(unsigned)((h + 255) / 256), 256, 0, s>>>(plane, h, w, xl, xr, out);
+  return hipGetLastError();
+}
+hipError_t block_unpack_cols(hipStream_t s, uint32_t *plane, size_t h, size_t w, const uint32_t *left, const uint32_t *right) {
+  if (h == 0 || w == 0 || (!left && !right)) return hipSuccess;
+  k_unpack_cols<<<(unsigned)((h + 255) / 256), 256, 0, s>>>(plane, h, w, left, right);
+  return hipGetLastError();
+}
+
 hipError_t block_export_boundary(hipStream_t s, const uint32_t *labels, int h, int w, int halo_flags, uint32_t rank, uint32_t *rows) {
   if (w == 0 || h == 0) return hipSuccess;
   k_block_export<<<(unsigned)((2 * (size_t)w + 255) / 256), 256, 0, s>>>(labels, h, w, halo_flags, rank, rows);

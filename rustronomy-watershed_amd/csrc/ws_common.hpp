@@ -153,6 +153,8 @@ hipError_t block_import_boundary(hipStream_t s, const uint32_t *table, uint32_t 
                                  uint32_t *labels, int h, int w, int halo_flags);
 hipError_t block_iota(hipStream_t s, uint32_t *p, size_t n, uint32_t first);      // p[i] = first + i
 hipError_t block_rows_differ(hipStream_t s, const uint32_t *a, const uint32_t *b, size_t n, uint32_t *flag);      // raises *flag, never clears it
+hipError_t block_pack_cols(hipStream_t s, const uint32_t *plane, size_t h, size_t w, size_t xl, size_t xr, uint32_t *out);      // out[0 .. h) = column xl, out[h .. 2h) = column xr
+hipError_t block_unpack_cols(hipStream_t s, uint32_t *plane, size_t h, size_t w, const uint32_t *left, const uint32_t *right);      // columns 0 / w - 1 (null: left alone)
 
 hipError_t flood_step(hipStream_t s, const uint8_t *img, size_t img_stride, const uint32_t *lin,
                       uint32_t *lout, int h, int w, uint32_t level, uint32_t *counter, bool padded = false);

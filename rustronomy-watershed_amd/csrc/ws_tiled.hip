@@ -99,11 +99,11 @@ struct Grow {      // a device buffer that only ever grows
 struct Rank {
   int rank = 0, device = 0;
   ws_ctx *ctx = nullptr;
-  Grow keys, labels, recv, rows, table, parent, img, seeds, colours, out64;
+  Grow keys, labels, recv, rows, table, parent, img, seeds, colours, out64, cols;
   uint32_t *flag = nullptr;           // device: 4 words (the exchange loop's stop word; reduce scratch)
   uint32_t *flag_host = nullptr;      // pinned mirror
   // what the LOCAL exchange steps read from their neighbours (published before the barrier)
-  const uint32_t *pub_first = nullptr, *pub_last = nullptr, *pub_send = nullptr;
+  const uint32_t *pub_first = nullptr, *pub_last = nullptr, *pub_send = nullptr, *pub_cols = nullptr;
   uint32_t pub_word = 0;
 };
 
@@ -182,6 +182,38 @@ struct Exchange {
     if (down) G_HIP(g, hipMemcpyAsync(recv + w, local(me.rank + 1)->pub_first, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     G_HIP(g, hipStreamSynchronize(stream()));
     // nobody goes on to rewrite its plane while a neighbour still reads it
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    return WS_OK;
+  }
+
+  // A block of a field cut in both directions: nb[] = the ranks above, below, left and right of me (-1: the field's edge).
+  // Sends my first / last OWNED row and column, receives the neighbours' into me.recv: [0, w) from above, [w, 2w) from below,
+  // [2w, 2w + h) from the left, [2w + h, 2w + 2h) from the right.  (Rows are contiguous; columns are packed into me.cols
+  // first.  The four corner cells of the halo ring are nobody's neighbours in a 4-connected stencil.)
+  int swap2d(const uint32_t *plane, size_t h, size_t w, const int nb[4]) {
+    const bool up = nb[0] >= 0, down = nb[1] >= 0, left = nb[2] >= 0, right = nb[3] >= 0;
+    const uint32_t *first = plane + (up ? w : 0), *last = plane + (h - 1 - (down ? 1 : 0)) * w;
+    uint32_t *recv = (uint32_t *)me.recv.p, *cols = (uint32_t *)me.cols.p;
+    G_HIP(g, block_pack_cols(stream(), plane, h, w, left ? 1 : 0, w - 1 - (right ? 1 : 0), cols));
+    if (g->is_rccl) {
+      RcclApi *n = rccl();
+      G_NCCL(g, n->GroupStart());
+      if (up) { G_NCCL(g, n->Send(first, w, ncclUint32, nb[0], g->comm, stream())); G_NCCL(g, n->Recv(recv, w, ncclUint32, nb[0], g->comm, stream())); }
+      if (down) { G_NCCL(g, n->Send(last, w, ncclUint32, nb[1], g->comm, stream())); G_NCCL(g, n->Recv(recv + w, w, ncclUint32, nb[1], g->comm, stream())); }
+      if (left) { G_NCCL(g, n->Send(cols, h, ncclUint32, nb[2], g->comm, stream())); G_NCCL(g, n->Recv(recv + 2 * w, h, ncclUint32, nb[2], g->comm, stream())); }
+      if (right) { G_NCCL(g, n->Send(cols + h, h, ncclUint32, nb[3], g->comm, stream())); G_NCCL(g, n->Recv(recv + 2 * w + h, h, ncclUint32, nb[3], g->comm, stream())); }
+      G_NCCL(g, n->GroupEnd());
+      return WS_OK;
+    }
+    G_HIP(g, hipStreamSynchronize(stream()));      // my packed columns are complete before anyone copies them
+    me.pub_first = first; me.pub_last = last; me.pub_cols = cols;
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    if (up) G_HIP(g, hipMemcpyAsync(recv, local(nb[0])->pub_last, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+    if (down) G_HIP(g, hipMemcpyAsync(recv + w, local(nb[1])->pub_first, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+    // (tiles of one tile row have the same rows: the neighbour's packed runs are h words long, its LAST column first comes second)
+    if (left) G_HIP(g, hipMemcpyAsync(recv + 2 * w, local(nb[2])->pub_cols + h, h * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+    if (right) G_HIP(g, hipMemcpyAsync(recv + 2 * w + h, local(nb[3])->pub_cols, h * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+    G_HIP(g, hipStreamSynchronize(stream()));
     if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
     return WS_OK;
   }
@@ -321,6 +353,51 @@ int tiled_rank(ws_group *g, Rank &me, size_t field_h, size_t w, size_t n_seeds_t
     ++rounds;
     G_WS(g, me, ws_block_merge_import(me.ctx, (const uint32_t *)me.table.p, (size_t)world * n_pairs, parent));
     G_WS(g, me, ws_block_merge_relabel(me.ctx, b.d_labels, n, parent, n_seeds_total, b.d_labels));      // elementwise: in place
+  }
+  G_HIP(g, hipStreamSynchronize(s));
+  if (rounds_out) *rounds_out = rounds;
+  return WS_OK;
+}
+
+// A field cut into py x px tiles (BASELINE config 5's "2-D tiles"; rank = ty * px + tx): every tile is a plane with a halo
+// ring of one pixel wherever it has a neighbour -- exactly the pixels the flood never writes, rows AND columns
+// (lib.rs:220-222), so the block steps of the general form run on it unchanged: painted seeds with their global colours,
+// rounds of { relax to local convergence; swap halo rows and columns; "did any rank change anything" }, then the same
+// rounds for the labels (one hop per sweep).  Halo traffic per round: 2 (w + h) words a tile.
+int tiled2d_rank(ws_group *g, Rank &me, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d &b, const ws_options *opt,
+                 uint32_t *rounds_out) {
+  G_HIP(g, hipSetDevice(me.device));
+  const int ty = me.rank / px, tx = me.rank % px;
+  size_t r0, r1, lo, hi, c0, c1, clo, chi;
+  if (ws_tile_rows(field_h, ty, py, &r0, &r1, &lo, &hi) || ws_tile_rows(field_w, tx, px, &c0, &c1, &clo, &chi))
+    return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row and one column per tile");
+  const size_t h = hi - lo, w = chi - clo, n = h * w;
+  const int nb[4] = {ty > 0 ? me.rank - px : -1, ty < py - 1 ? me.rank + px : -1, tx > 0 ? me.rank - 1 : -1, tx < px - 1 ? me.rank + 1 : -1};
+  uint32_t rounds = 0;
+  Exchange x{g, me};
+  int rc;
+  if ((rc = grow(g, me.keys, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(g, me.recv, (2 * w + 2 * h + 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(g, me.cols, (2 * h + 1) * sizeof(uint32_t)))) return rc;
+  uint32_t *keys = (uint32_t *)me.keys.p, *recv = (uint32_t *)me.recv.p;
+  hipStream_t s = me.ctx->stream;
+  G_WS(g, me, ws_block_init(me.ctx, h, w, b.d_seeds_rc, b.d_colours, b.n_seeds, keys, b.d_labels));
+  for (int phase = 0; phase < 2; ++phase) {
+    uint32_t *plane = phase == 0 ? keys : b.d_labels;
+    for (;;) {
+      int changed = 0;
+      if (phase == 0) G_WS(g, me, ws_block_relax(me.ctx, b.d_img, h, w, b.img_stride, opt->max_water_level, keys, &changed));
+      else G_WS(g, me, ws_block_resolve(me.ctx, keys, b.d_labels, h, w, &changed));
+      if ((rc = x.swap2d(plane, h, w, nb))) return rc;
+      if (nb[0] >= 0) G_HIP(g, hipMemcpyAsync(plane, recv, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+      if (nb[1] >= 0) G_HIP(g, hipMemcpyAsync(plane + (h - 1) * w, recv + w, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+      // (columns after rows: a halo column's first / last cell is a corner of the ring, read by nobody)
+      G_HIP(g, block_unpack_cols(s, plane, h, w, nb[2] >= 0 ? recv + 2 * w : nullptr, nb[3] >= 0 ? recv + 2 * w + h : nullptr));
+      uint32_t any = 0;
+      if ((rc = x.reduce_host(changed ? 1u : 0u, true, &any))) return rc;
+      ++rounds;
+      if (!any) break;
+    }
   }
   G_HIP(g, hipStreamSynchronize(s));
   if (rounds_out) *rounds_out = rounds;
@@ -547,6 +624,38 @@ int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seed
   rc = for_local_ranks(g, [&](Rank &me) {
     const size_t i = (size_t)(me.rank - g->first_local);
     return tiled_rank(g, me, field_h, w, n_seeds_total, blocks[i], opt, merging, &rounds[i]);
+  });
+  if (exchange_rounds) *exchange_rounds = rounds[0];
+  return rc;
+}
+
+int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows, size_t *cols) {
+  if (py < 1 || px < 1 || rank < 0 || rank >= py * px || !rows || !cols) return WS_ERR_BAD_ARG;
+  int rc = ws_tile_rows(h, rank / px, py, rows, rows + 1, rows + 2, rows + 3);
+  if (rc == WS_OK) rc = ws_tile_rows(w, rank % px, px, cols, cols + 1, cols + 2, cols + 3);
+  return rc;
+}
+
+int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d *blocks, const ws_options *opt,
+                              uint32_t *exchange_rounds) {
+  int rc = check_group_call(g, opt);
+  if (rc) return rc;
+  if (!blocks) return gfail(g, WS_ERR_BAD_ARG, "blocks pointer is null");
+  if (py < 1 || px < 1 || py * px != g->world) return gfail(g, WS_ERR_BAD_ARG, "py * px must be the group's number of ranks");
+  if (opt->edge_correction) return gfail(g, WS_ERR_UNSUPPORTED, "ws_segment_tiled2d_device takes the field as it is: pad it first");
+  if (field_h < (size_t)py || field_w < (size_t)px) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row and one column per tile");
+  for (size_t i = 0; i < g->ranks.size(); ++i) {
+    const ws_tile_block2d &b = blocks[i];
+    size_t rws[4], cls[4];
+    if (ws_tile_grid(field_h, field_w, g->first_local + (int)i, py, px, rws, cls)) return gfail(g, WS_ERR_BAD_ARG, "bad tile grid");
+    if (!b.d_img || !b.d_labels || b.img_stride < cls[3] - cls[2] || (b.n_seeds && (!b.d_seeds_rc || !b.d_colours)))
+      return gfail(g, WS_ERR_BAD_ARG, "bad block descriptor");
+  }
+  if (exchange_rounds) *exchange_rounds = 0;
+  std::vector<uint32_t> rounds(g->ranks.size(), 0);
+  rc = for_local_ranks(g, [&](Rank &me) {
+    const size_t i = (size_t)(me.rank - g->first_local);
+    return tiled2d_rank(g, me, field_h, field_w, py, px, blocks[i], opt, &rounds[i]);
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];
   return rc;

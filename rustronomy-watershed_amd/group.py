@@ -119,6 +119,45 @@ class Group:
                                                        ctypes.byref(rounds)), "ws_segment_tiled_device")
         return rounds.value
 
+    # ---- one field in py x px tiles (both directions) ------------------------------------------------------------------------------
+    @staticmethod
+    def tile_grid(h, w, rank, py, px):
+        rows, cols = (ctypes.c_size_t * 4)(), (ctypes.c_size_t * 4)()
+        rc = _ffi.lib().ws_tile_grid(h, w, rank, py, px, rows, cols)
+        if rc != 0:
+            raise ValueError(f"a {h} x {w} field cannot be cut into {py} x {px} tiles")
+        return tuple(rows), tuple(cols)
+
+    def make_blocks2d(self, field, seeds, py, px):
+        """Descriptors of the LOCAL ranks' tiles of `field` (uint8 (H, W) tensor on the ranks' device: a tile's image is a view
+        into it) with the global seed list `seeds` (int32 (n, 2), any order).  Returns (ctypes array, [(rows, cols, labels)], keep)."""
+        H, W = field.shape
+        blocks = (_ffi.TileBlock2D * self.n_local)()
+        spans, keep = [], []
+        colours_all = torch.arange(1, seeds.shape[0] + 1, dtype=torch.int32, device=seeds.device)
+        for i in range(self.n_local):
+            rows, cols = self.tile_grid(H, W, self.first_local + i, py, px)
+            (r0, r1, lo, hi), (c0, c1, clo, chi) = rows, cols
+            view = field[lo:hi, clo:chi]
+            inside = (seeds[:, 0] >= lo) & (seeds[:, 0] < hi) & (seeds[:, 1] >= clo) & (seeds[:, 1] < chi)
+            loc = seeds[inside].to(field.device).clone()
+            loc[:, 0] -= lo
+            loc[:, 1] -= clo
+            col = colours_all[inside].to(field.device).contiguous()
+            lab = torch.empty((hi - lo, chi - clo), dtype=torch.int32, device=field.device)
+            keep += [view, loc, col, lab]
+            spans.append((rows, cols, lab))
+            ns = int(loc.shape[0])
+            blocks[i] = _ffi.TileBlock2D(view.data_ptr(), field.stride(0), loc.data_ptr() if ns else None, col.data_ptr() if ns else None, ns, lab.data_ptr())
+        torch.cuda.synchronize()
+        return blocks, spans, keep
+
+    def segment_tiled2d_device(self, field_h, field_w, py, px, blocks, max_level=254):
+        opt = _ffi.Options(max_level)
+        rounds = ctypes.c_uint32(0)
+        self._check(_ffi.lib().ws_segment_tiled2d_device(self._h, field_h, field_w, py, px, blocks, ctypes.byref(opt), ctypes.byref(rounds)), "ws_segment_tiled2d_device")
+        return rounds.value
+
     # ---- a batch of independent slices ------------------------------------------------------------------------------------------
     def segment_batch(self, h, w, parts, max_level=254):
         """parts: one (cube (S, h, w) uint8, seeds (n, 2) int32, offsets list of S + 1, labels (S, h, w) int32) per LOCAL rank."""

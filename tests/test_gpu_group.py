@@ -265,3 +265,94 @@ def test_batch_group_equals_slice_by_slice(pkg):
         for j, k in enumerate(mine):
             assert bool((lab[j] == want[k]).all()), k
     g.close()
+
+
+# ---- 2-D tiles (BASELINE config 5's wording): the field cut in both directions -------------------------------------------------
+
+def _tiled2d(pkg, img, seeds, py, px, max_level=254):
+    import torch
+    grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
+    g = grp_mod.Group.local(py * px)
+    dev = torch.device("cuda", 0)
+    field = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+    s = torch.from_numpy(np.asarray(seeds, dtype=np.int64).reshape(-1, 2).astype(np.int32)).to(dev)
+    blocks, spans, keep = g.make_blocks2d(field, s, py, px)
+    rounds = g.segment_tiled2d_device(img.shape[0], img.shape[1], py, px, blocks, max_level=max_level)
+    out = np.zeros(img.shape, dtype=np.uint32)
+    halo_ok = True
+    for (r0, r1, lo, hi), (c0, c1, clo, chi), lab in spans:
+        L = lab.cpu().numpy().view(np.uint32)
+        out[r0:r1, c0:c1] = L[r0 - lo:r1 - lo, c0 - clo:c1 - clo]
+    # every tile's halo ring holds the owner's labels (the four corner cells of the ring belong to nobody's stencil)
+    for (r0, r1, lo, hi), (c0, c1, clo, chi), lab in spans:
+        L = lab.cpu().numpy().view(np.uint32)
+        if lo < r0:
+            halo_ok &= bool((L[0, c0 - clo:c1 - clo] == out[lo, c0:c1]).all())
+        if hi > r1:
+            halo_ok &= bool((L[-1, c0 - clo:c1 - clo] == out[hi - 1, c0:c1]).all())
+        if clo < c0:
+            halo_ok &= bool((L[r0 - lo:r1 - lo, 0] == out[r0:r1, clo]).all())
+        if chi > c1:
+            halo_ok &= bool((L[r0 - lo:r1 - lo, -1] == out[r0:r1, chi - 1]).all())
+    g.close()
+    return out, rounds, halo_ok
+
+
+@pytest.mark.parametrize("py,px", [(2, 2), (2, 3), (3, 2), (1, 4), (4, 1)])
+@pytest.mark.parametrize("kind", ["noise", "smooth", "few"])
+def test_field_in_2d_tiles_equals_the_single_domain_transform(pkg, py, px, kind):
+    # ws_segment_tiled2d_device on a local group: halo rows AND columns, the general form's block steps on every tile
+    shape = (301, 422) if kind == "noise" else (260, 517)
+    img = cases.field(*shape, 41) if kind == "noise" else cases.smooth_field(*shape, 13, octaves=5)
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    if kind == "few":
+        seeds = seeds[:: max(len(seeds) // 4, 1)][:4]      # floods that cross every tile boundary, several times
+    else:
+        seeds = seeds[np.random.default_rng(3).permutation(len(seeds))]      # any order: colours are indices of THIS list
+    want = ol.segment_arrival(img, seeds)
+    got, rounds, halo_ok = _tiled2d(pkg, img, seeds, py, px)
+    assert (got == want).all(), (py, px, kind, int((got != want).sum()))
+    assert halo_ok and rounds >= 2
+
+
+def test_2d_tiles_argument_errors_and_low_levels(pkg):
+    import torch
+    grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
+    g = grp_mod.Group.local(4)
+    field = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+    s = torch.zeros((0, 2), dtype=torch.int32, device="cuda")
+    blocks, _, _keep = g.make_blocks2d(field, s, 2, 2)
+    with pytest.raises(RuntimeError):
+        g.segment_tiled2d_device(64, 64, 3, 2, blocks)          # 3 x 2 tiles on a group of four ranks
+    with pytest.raises(ValueError):
+        grp_mod.Group.tile_grid(1, 64, 0, 2, 2)                 # fewer rows than tile rows
+    g.close()
+    img = cases.smooth_field(200, 333, 5, octaves=5)
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    got, _, halo_ok = _tiled2d(pkg, img, seeds, 2, 2, max_level=90)
+    assert halo_ok and (got == ol.segment_arrival(img, seeds, max_level=90)).all()
+
+
+def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
+    import torch
+    grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
+    dev_mod = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev_mod.DeviceEngine(0)
+    # 2048 x 3072 random field in 2 x 3 tiles against the single-domain transform (oracle-checked at size elsewhere)
+    img = eng.random_field(2048, 3072, 17)
+    seeds = eng.find_local_minima(img)
+    want = eng.segment(img, seeds).clone()
+    g = grp_mod.Group.local(6)
+    blocks, spans, keep = g.make_blocks2d(img, seeds, 2, 3)
+    g.segment_tiled2d_device(2048, 3072, 2, 3, blocks)
+    for (r0, r1, lo, hi), (c0, c1, clo, chi), lab in spans:
+        assert bool((lab[r0 - lo:r1 - lo, c0 - clo:c1 - clo] == want[r0:r1, c0:c1]).all())
+    g.close()
+    # a group of ONE rank made by RCCL: 1 x 1 tiles -- no neighbour, but the flag goes through ncclAllReduce of the real library
+    g = grp_mod.Group.rccl(0, 0, 1, lambda raw: raw)
+    small = eng.random_field(256, 384, 3)
+    ss = eng.find_local_minima(small)
+    blocks, spans, keep = g.make_blocks2d(small, ss, 1, 1)
+    g.segment_tiled2d_device(256, 384, 1, 1, blocks)
+    assert bool((spans[0][2] == eng.segment(small, ss)).all())
+    g.close()
