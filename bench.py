@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the one CPU run of the bench field itself (~45 s at 8192^2)")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / secondary / cpu_baseline")
     ap.add_argument("--local-ranks", type=int, default=1, help="c5 on ONE process: virtual ranks of the local group (1: the field whole)")
+    ap.add_argument("--tiles", default="", help="c5: PYxPX -- the field cut in both directions (ws_segment_tiled2d_device) instead of row blocks; PY * PX = the ranks")
     ap.add_argument("--contexts", type=int, default=4, help="headline: engine contexts that take turns, each on its own stream (1: as --no-pipeline)")
     ap.add_argument("--one-stream", action="store_true", help="headline: all contexts on one stream (transforms queue up, never overlap)")
     ap.add_argument("--no-pipeline", action="store_true", help="headline: one context, every transform waited for before the next is queued (the default takes turns on two contexts: ws_segment_device_begin / _end)")
@@ -430,18 +431,29 @@ def run(args):
             full = eng.random_field(H, W, 5)                # every rank generates the field and keeps its rows (+ halo rows)
             all_seeds = eng.find_local_minima(full).clone() # global list; a rank's seeds are a contiguous range of it
             n_all = int(all_seeds.shape[0])
-            blocks, spans, keep = grp.make_blocks(H, lambda lo, hi, r: full[lo:hi].contiguous() if grp.world > 1 else full, all_seeds)
-            r0, r1 = spans[0][0], spans[0][1]
-            if grp.world > 1:
-                del full
+            tiles2d = tuple(int(v) for v in args.tiles.lower().split("x")) if args.tiles else None
+            if tiles2d:
+                # the field cut in both directions (py x px tiles, halo rows and columns; the general form's block steps)
+                assert tiles2d[0] * tiles2d[1] == grp.world, f"--tiles {args.tiles}: {grp.world} ranks"
+                blocks, spans, keep = grp.make_blocks2d(full, all_seeds, tiles2d[0], tiles2d[1])
+                r0, r1 = spans[0][0][0], spans[0][0][1]
+
+                def step():
+                    rounds_seen.append(grp.segment_tiled2d_device(H, W, tiles2d[0], tiles2d[1], blocks))
+            else:
+                blocks, spans, keep = grp.make_blocks(H, lambda lo, hi, r: full[lo:hi].contiguous() if grp.world > 1 else full, all_seeds)
+                r0, r1 = spans[0][0], spans[0][1]
+                if grp.world > 1:
+                    del full
+
+                def step():
+                    rounds_seen.append(grp.segment_tiled_device(H, W, n_all, blocks))
             del all_seeds
             torch.cuda.empty_cache()
-
-            def step():
-                rounds_seen.append(grp.segment_tiled_device(H, W, n_all, blocks))
             labels = None
-            how = (f"ws_segment_tiled_device, RCCL group of {world} ranks (grouped ncclSend/ncclRecv halo rows, 1-word ncclAllReduce, ncclAllGather of the boundary table)"
-                   if world > 1 else f"ws_segment_tiled_device, local group of {vranks} rank(s) on one device")
+            entry = f"ws_segment_tiled2d_device ({args.tiles} tiles, halo rows and columns)" if tiles2d else "ws_segment_tiled_device"
+            how = (f"{entry}, RCCL group of {world} ranks (grouped ncclSend/ncclRecv halos, 1-word ncclAllReduce" + ("" if tiles2d else ", ncclAllGather of the boundary table") + ")"
+                   if world > 1 else f"{entry}, local group of {vranks} rank(s) on one device")
         else:
             # rehearsal with more ranks than GPUs: RCCL refuses two ranks on one device, so the caller-driven form
             # (distributed.py: the same block steps, collectives over gloo) stands in
@@ -463,8 +475,9 @@ def run(args):
         n_seeds = n_all
         px_per_step_all_ranks = H * W
         scaling = "strong"
-        workload = (f"one {H}x{W} u8 random field, segmenting, row blocks of {r1 - r0} rows per rank with 1-row halos; {how}")
-        parallelism = f"row-blocked tiles x{world if world > 1 else vranks}"
+        shape_txt = f"{args.tiles} tiles with a 1-pixel halo ring" if (use_c_group and args.tiles) else f"row blocks of {r1 - r0} rows per rank with 1-row halos"
+        workload = (f"one {H}x{W} u8 random field, segmenting, {shape_txt}; {how}")
+        parallelism = f"{'2-D' if (use_c_group and args.tiles) else 'row-blocked'} tiles x{world if world > 1 else vranks}"
         units = {"rows_per_gpu": r1 - r0}
 
     for _ in range(args.warmup):
