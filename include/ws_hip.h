@@ -460,6 +460,10 @@ typedef struct ws_tile_block2d {
 int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows /* 4 */, size_t *cols /* 4 */);
 int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d *blocks,
                               const ws_options *opt, uint32_t *exchange_rounds);
+/* ... with host buffers in and out, as ws_segment_tiled: every rank of the group calls it with the SAME arguments, uploads its
+ * tile, takes its seeds (any list), writes the rectangle it owns of out_labels.  Edge correction pads the field first. */
+int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t row_stride, const uint64_t *seeds_rc,
+                       size_t n_seeds, const ws_options *opt, int py, int px, uint64_t *out_labels, uint32_t *exchange_rounds);
 
 /* BASELINE config C4 over a group: a batch of independent slices, slice i on rank i % world, a rank's slices as ONE stacked
  * transform (ws_segment_batch_device) -- no exchange step at all.  One descriptor per LOCAL rank: the rank's own slices,

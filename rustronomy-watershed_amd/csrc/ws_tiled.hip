@@ -759,6 +759,77 @@ int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t
   return rc;
 }
 
+// ... in py x px tiles: every local rank uploads its tile of the (padded) image, takes the seeds that fall on its plane with
+// their colours (index + 1), runs tiled2d_rank and writes the rectangle it owns of out_labels.
+int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc, size_t n_seeds,
+                       const ws_options *opt, int py, int px, uint64_t *out_labels, uint32_t *exchange_rounds) {
+  int rc = check_group_call(g, opt);
+  if (rc) return rc;
+  if ((!img && h * w) || (!seeds_rc && n_seeds) || stride < w) return gfail(g, WS_ERR_BAD_ARG, "bad argument");
+  if (py < 1 || px < 1 || py * px != g->world) return gfail(g, WS_ERR_BAD_ARG, "py * px must be the group's number of ranks");
+  const size_t e = opt->edge_correction ? 2 : 0, ph = h + e, pw = w + e, shift = opt->edge_correction && opt->seed_shift ? 1 : 0;
+  if (!out_labels && ph * pw) return gfail(g, WS_ERR_BAD_ARG, "out_labels is null");
+  if (n_seeds >= 0x7FFFFFFFull) return gfail(g, WS_ERR_TOO_LARGE, "too many seeds");
+  if (ph > 0x7FFFFFF0ull || pw > 0x7FFFFFF0ull) return gfail(g, WS_ERR_TOO_LARGE, "plane too large");
+  if (ph < (size_t)py || pw < (size_t)px) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row and one column per tile");
+  if (exchange_rounds) *exchange_rounds = 0;
+  for (size_t i = 0; i < n_seeds; ++i)      // the reference indexes the (padded) plane with the caller's coordinates and panics outside it (lib.rs:1675-1677)
+    if (seeds_rc[2 * i] + shift >= ph || seeds_rc[2 * i + 1] + shift >= pw) return gfail(g, WS_ERR_SEED_OOB, "seed outside the label plane (the reference panics: lib.rs:1676)");
+  ws_options plain = *opt;
+  plain.edge_correction = 0;      // the tiles hold the padded plane's own pixels
+  plain.seed_shift = 0;
+  std::vector<uint32_t> rounds(g->ranks.size(), 0);
+  rc = for_local_ranks(g, [&](Rank &me) -> int {
+    G_HIP(g, hipSetDevice(me.device));
+    hipStream_t s = me.ctx->stream;
+    size_t rw[4], cl[4];
+    int rc2 = ws_tile_grid(ph, pw, me.rank, py, px, rw, cl);
+    if (rc2) return gfail(g, rc2, "bad tile grid");
+    const size_t r0 = rw[0], r1 = rw[1], lo = rw[2], hi = rw[3], c0 = cl[0], c1 = cl[1], clo = cl[2], chi = cl[3];
+    const size_t bh = hi - lo, bw = chi - clo, bn = bh * bw;
+    if ((rc2 = grow(g, me.img, bn ? bn : 1))) return rc2;
+    if ((rc2 = grow(g, me.labels, (bn ? bn : 1) * sizeof(uint32_t)))) return rc2;
+    // padded pixel (p, q) holds image pixel (p - e / 2, q - e / 2); the ring of an edge-corrected plane is zero
+    G_HIP(g, hipMemsetAsync(me.img.p, 0, bn ? bn : 1, s));
+    const size_t o = e / 2;
+    const size_t p0 = std::max(lo, o), p1 = std::min(hi, h + o), q0 = std::max(clo, o), q1 = std::min(chi, w + o);
+    if (p1 > p0 && q1 > q0)
+      G_HIP(g, hipMemcpy2DAsync((uint8_t *)me.img.p + (p0 - lo) * bw + (q0 - clo), bw, img + (p0 - o) * stride + (q0 - o), stride, q1 - q0, p1 - p0, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> loc, col;
+    for (size_t i = 0; i < n_seeds; ++i) {
+      const uint64_t row = seeds_rc[2 * i] + shift, cc = seeds_rc[2 * i + 1] + shift;
+      if (row >= lo && row < hi && cc >= clo && cc < chi) { loc.push_back((uint32_t)(row - lo)); loc.push_back((uint32_t)(cc - clo)); col.push_back((uint32_t)i + 1u); }
+    }
+    const size_t ns = col.size();
+    if ((rc2 = grow(g, me.seeds, (ns ? ns : 1) * 2 * sizeof(uint32_t)))) return rc2;
+    if ((rc2 = grow(g, me.colours, (ns ? ns : 1) * sizeof(uint32_t)))) return rc2;
+    if (ns) G_HIP(g, hipMemcpyAsync(me.seeds.p, loc.data(), ns * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (ns) G_HIP(g, hipMemcpyAsync(me.colours.p, col.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    G_HIP(g, hipStreamSynchronize(s));
+    ws_tile_block2d b{};
+    b.d_img = (const uint8_t *)me.img.p;
+    b.img_stride = bw;
+    b.d_seeds_rc = (const uint32_t *)me.seeds.p;
+    b.d_colours = (const uint32_t *)me.colours.p;
+    b.n_seeds = ns;
+    b.d_labels = (uint32_t *)me.labels.p;
+    const size_t i = (size_t)(me.rank - g->first_local);
+    if ((rc2 = tiled2d_rank(g, me, ph, pw, py, px, b, &plain, &rounds[i]))) return rc2;
+    // ---- the rectangle it owns, widened, into the caller's plane
+    const size_t oh = r1 - r0, ow = c1 - c0;
+    if (oh * ow) {
+      if ((rc2 = grow(g, me.out64, bn * sizeof(uint64_t)))) return rc2;
+      G_HIP(g, widen_labels(s, (const uint32_t *)me.labels.p, (uint64_t *)me.out64.p, bn));
+      G_HIP(g, hipMemcpy2DAsync(out_labels + r0 * pw + c0, pw * sizeof(uint64_t), (const uint64_t *)me.out64.p + (r0 - lo) * bw + (c0 - clo), bw * sizeof(uint64_t),
+                                ow * sizeof(uint64_t), oh, hipMemcpyDeviceToHost, s));
+      G_HIP(g, hipStreamSynchronize(s));
+    }
+    return WS_OK;
+  });
+  if (exchange_rounds) *exchange_rounds = rounds[0];
+  return rc;
+}
+
 int ws_segment_batch_group(ws_group *g, size_t h, size_t w, const ws_batch_part *parts, const ws_options *opt, size_t *failed_rank,
                            size_t *failed_slice) {
   if (failed_rank) *failed_rank = 0;

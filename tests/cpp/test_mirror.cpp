@@ -254,6 +254,27 @@ static int group_sequence_checks() {
   CHECK(ws_segment_tiled(g, img.data(), H, W, W, rc_pairs.data(), n, &o, 1, out.data(), nullptr) == WS_OK);
   CHECK(ws_or_merge_arrival(img.data(), H, W, rc_pairs.data(), n, 90, 0, want.data(), nullptr, nullptr) == 0);
   CHECK(out == want);
+  // the same field in 2 x 2 tiles (halo rows and columns) on a group of four, plain and with edge correction
+  {
+    ws_group *g4 = nullptr;
+    const int dev4[4] = {0, 0, 0, 0};
+    CHECK(ws_group_create_local(4, dev4, &g4) == WS_OK);
+    size_t rows[4], cols[4];
+    CHECK(ws_tile_grid(H, W, 3, 2, 2, rows, cols) == WS_OK && rows[0] == 150 && rows[2] == 149 && cols[0] == 128 && cols[2] == 127 && cols[3] == 256);
+    ws_options o2;
+    ws_options_default(&o2);
+    uint32_t r2 = 0;
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, out.data(), &r2) == WS_OK);
+    CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 0, want.data(), nullptr) == 0);
+    CHECK(out == want && r2 >= 2);
+    o2.edge_correction = 1;
+    std::vector<uint64_t> oute((H + 2) * (W + 2)), wante((H + 2) * (W + 2));
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, oute.data(), nullptr) == WS_OK);
+    CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 1, wante.data(), nullptr) == 0);
+    CHECK(oute == wante);
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 3, 2, oute.data(), nullptr) == WS_ERR_BAD_ARG);
+    ws_group_destroy(g4);
+  }
   const uint64_t bad[2] = {H, 0};
   CHECK(ws_segment_tiled(g, img.data(), H, W, W, bad, 1, &o, 0, out.data(), nullptr) == WS_ERR_SEED_OOB);
   CHECK(std::strlen(ws_group_last_error(g)) > 0);
