@@ -439,7 +439,7 @@ def run(args):
                 r0, r1 = spans[0][0][0], spans[0][0][1]
 
                 def step():
-                    rounds_seen.append(grp.segment_tiled2d_device(H, W, tiles2d[0], tiles2d[1], blocks))
+                    rounds_seen.append(grp.segment_tiled2d_device(H, W, tiles2d[0], tiles2d[1], blocks, n_seeds_total=n_all))
             else:
                 blocks, spans, keep = grp.make_blocks(H, lambda lo, hi, r: full[lo:hi].contiguous() if grp.world > 1 else full, all_seeds)
                 r0, r1 = spans[0][0], spans[0][1]

@@ -448,7 +448,8 @@ int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seed
  * in each direction).  One descriptor per LOCAL rank; seeds carry their colours (index in the caller's list + 1,
  * lib.rs:1670-1672: a tile's seeds are no contiguous range of the list).  The exchange is halo rows AND columns, 2 (w + h)
  * words a tile and round; the block steps are the general form's (painted seeds, relaxation rounds, label rounds: the
- * seed-table / boundary-table shortcuts of the row-block form are not built for tiles).  Segmenting transform only. */
+ * seed-table / boundary-table shortcuts of the row-block form are not built for tiles).  merging != 0: the MERGING transform's
+ * final canonical labels (one more gather: (colour, root) pairs of every tile's outermost rows and columns). */
 typedef struct ws_tile_block2d {
   const uint8_t *d_img;        /* the tile's plane [lo, hi) x [clo, chi) of the field, on the rank's device */
   size_t img_stride;           /* >= chi - clo (a view into the whole field works) */
@@ -458,12 +459,13 @@ typedef struct ws_tile_block2d {
   uint32_t *d_labels;          /* out: (hi - lo) x (chi - clo) u32 */
 } ws_tile_block2d;
 int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows /* 4 */, size_t *cols /* 4 */);
-int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d *blocks,
-                              const ws_options *opt, uint32_t *exchange_rounds);
+int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total,
+                              const ws_tile_block2d *blocks, const ws_options *opt, int merging, uint32_t *exchange_rounds);
 /* ... with host buffers in and out, as ws_segment_tiled: every rank of the group calls it with the SAME arguments, uploads its
  * tile, takes its seeds (any list), writes the rectangle it owns of out_labels.  Edge correction pads the field first. */
 int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t row_stride, const uint64_t *seeds_rc,
-                       size_t n_seeds, const ws_options *opt, int py, int px, uint64_t *out_labels, uint32_t *exchange_rounds);
+                       size_t n_seeds, const ws_options *opt, int py, int px, int merging, uint64_t *out_labels,
+                       uint32_t *exchange_rounds);
 
 /* BASELINE config C4 over a group: a batch of independent slices, slice i on rank i % world, a rank's slices as ONE stacked
  * transform (ws_segment_batch_device) -- no exchange step at all.  One descriptor per LOCAL rank: the rank's own slices,

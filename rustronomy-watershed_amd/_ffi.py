@@ -153,8 +153,8 @@ SIGNATURES = {
     "ws_segment_tiled": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, vp, u32p]),
     "ws_segment_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, ctypes.POINTER(TileBlock), ctypes.POINTER(Options), ctypes.c_int, u32p]),
     "ws_tile_grid": (ctypes.c_int, [sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, szp, szp]),
-    "ws_segment_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(TileBlock2D), ctypes.POINTER(Options), u32p]),
-    "ws_segment_tiled2d": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, ctypes.c_int, vp, u32p]),
+    "ws_segment_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(TileBlock2D), ctypes.POINTER(Options), ctypes.c_int, u32p]),
+    "ws_segment_tiled2d": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, u32p]),
     "ws_segment_batch_group": (ctypes.c_int, [vp, sz, sz, ctypes.POINTER(BatchPart), ctypes.POINTER(Options), szp, szp]),
 }
 

@@ -713,8 +713,9 @@ hipError_t fold_and_add_sd(hipStream_t s, const uint32_t *hooked, const uint32_t
 // rows and its halo rows, the root of c in ITS forest: k_block_colour_roots writes the pairs (c, root(c)), one
 // all-gather, and every rank joins all gathered pairs into its own forest (union_edges).  Roots are class minima
 // (union-by-min), so the merged root is the smallest seed colour of the whole lake: the canonical id.
+// (col0, W: a tile of a field cut in both directions holds the field's columns [col0, col0 + w); a row block: col0 = 0, W = w)
 __global__ __launch_bounds__(256) void k_block_union_pixels(const uint32_t *__restrict__ labels, int h, int w, int row0, int H,
-                                                            uint32_t *parent) {
+                                                            uint32_t *parent, int col0, int W) {
   const size_t n = (size_t)h * w;
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -722,22 +723,47 @@ __global__ __launch_bounds__(256) void k_block_union_pixels(const uint32_t *__re
     const uint32_t lp = labels[p];
     if (lp == 0u) continue;                              // at the final level a pixel is coloured iff its label is not 0
     const int y = (int)(p / (size_t)w), x = (int)(p - (size_t)y * w);
-    const bool ip = interior(row0 + y, x, H, w);
+    const bool ip = interior(row0 + y, col0 + x, H, W);
     if (x + 1 < w) {
       const uint32_t lq = labels[p + 1];
-      if (lq != 0u && lq != lp && (ip || interior(row0 + y, x + 1, H, w))) (void)uf_union(parent, lp, lq);
+      if (lq != 0u && lq != lp && (ip || interior(row0 + y, col0 + x + 1, H, W))) (void)uf_union(parent, lp, lq);
     }
     if (y + 1 < h) {
       const uint32_t lq = labels[p + w];
-      if (lq != 0u && lq != lp && (ip || interior(row0 + y + 1, x, H, w))) (void)uf_union(parent, lp, lq);
+      if (lq != 0u && lq != lp && (ip || interior(row0 + y + 1, col0 + x, H, W))) (void)uf_union(parent, lp, lq);
     }
   }
 }
 
-hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent) {
+hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent, int col0, int W) {
   if (h == 0 || w == 0) return hipSuccess;
   const size_t n = (size_t)h * w;
-  k_block_union_pixels<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(labels, h, w, row0, H, parent);
+  k_block_union_pixels<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(labels, h, w, row0, H, parent, col0, W < 0 ? w : W);
+  return hipGetLastError();
+}
+
+// ... and of a tile: its two outermost rows AND columns on every side (4 w + 4 h pairs, then (0, 0) up to n_pairs: tiles of
+// a grid differ by a row or a column, an all-gather wants equal parts)
+__global__ void k_block_colour_roots2d(const uint32_t *__restrict__ labels, int h, int w, uint32_t *parent, uint2 *pairs, size_t n_pairs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  uint32_t c = 0;
+  if (i < (size_t)4 * w) {
+    const int k = (int)(i / (size_t)w), x = (int)(i - (size_t)k * w);
+    const int rows[4] = {0, min(1, h - 1), max(h - 2, 0), h - 1};
+    c = labels[(size_t)rows[k] * w + x];
+  } else if (i < (size_t)4 * w + (size_t)4 * h) {
+    const size_t j = i - (size_t)4 * w;
+    const int k = (int)(j / (size_t)h), y = (int)(j - (size_t)k * h);
+    const int cols[4] = {0, min(1, w - 1), max(w - 2, 0), w - 1};
+    c = labels[(size_t)y * w + cols[k]];
+  }
+  pairs[i] = c ? make_uint2(c, uf_find(parent, c)) : make_uint2(0u, 0u);
+}
+
+hipError_t block_colour_roots2d(hipStream_t s, const uint32_t *labels, int h, int w, uint32_t *parent, uint2 *pairs, size_t n_pairs) {
+  if (n_pairs == 0) return hipSuccess;
+  k_block_colour_roots2d<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(labels, h, w, parent, pairs, n_pairs);
   return hipGetLastError();
 }
 

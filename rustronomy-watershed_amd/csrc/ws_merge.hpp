@@ -74,7 +74,8 @@ hipError_t fold_and_add_sd(hipStream_t s, const uint32_t *hooked, const uint32_t
 // merging across the row blocks of a tiled field: joins the touching colours of one block (seam pairs to its halo rows
 // included; row0 = field row of the block's first local row, H = rows of the whole field), and the (colour, root) pairs
 // of the block's boundary and halo rows (4 * w of them) that the ranks exchange
-hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent);
+hipError_t block_union_pixels(hipStream_t s, const uint32_t *labels, int h, int w, int row0, int H, uint32_t *parent, int col0 = 0, int W = -1);      // (a tile: its first column in the field, the field's width)
+hipError_t block_colour_roots2d(hipStream_t s, const uint32_t *labels, int h, int w, uint32_t *parent, uint2 *pairs, size_t n_pairs);      // rows and columns: 4 w + 4 h pairs, (0, 0) after them
 hipError_t block_colour_roots(hipStream_t s, const uint32_t *labels, int h, int w, uint32_t *parent, uint2 *pairs);
 
 // final-only path: union every crossing edge of the whole image in one launch

@@ -364,8 +364,8 @@ int tiled_rank(ws_group *g, Rank &me, size_t field_h, size_t w, size_t n_seeds_t
 // (lib.rs:220-222), so the block steps of the general form run on it unchanged: painted seeds with their global colours,
 // rounds of { relax to local convergence; swap halo rows and columns; "did any rank change anything" }, then the same
 // rounds for the labels (one hop per sweep).  Halo traffic per round: 2 (w + h) words a tile.
-int tiled2d_rank(ws_group *g, Rank &me, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d &b, const ws_options *opt,
-                 uint32_t *rounds_out) {
+int tiled2d_rank(ws_group *g, Rank &me, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total, const ws_tile_block2d &b,
+                 const ws_options *opt, int merging, uint32_t *rounds_out) {
   G_HIP(g, hipSetDevice(me.device));
   const int ty = me.rank / px, tx = me.rank % px;
   size_t r0, r1, lo, hi, c0, c1, clo, chi;
@@ -398,6 +398,26 @@ int tiled2d_rank(ws_group *g, Rank &me, size_t field_h, size_t field_w, int py, 
       ++rounds;
       if (!any) break;
     }
+  }
+  if (merging) {
+    // as the row blocks' (ws_block_merge_*): a union-find over all seed colours per rank, the touching colours of the tile
+    // joined under find_merge's rule (one pixel of a pair interior IN THE WHOLE FIELD), then ONE gather of (colour, local
+    // root) pairs of the tile's two outermost rows and columns on every side, every pair joined, the relabel
+    const size_t max_h = (field_h + (size_t)py - 1) / (size_t)py + 2, max_w = (field_w + (size_t)px - 1) / (size_t)px + 2;
+    const size_t n_pairs = 4 * max_w + 4 * max_h;      // the same for every rank: a tile's own 4 w + 4 h, then (0, 0)
+    const int world = g->world;
+    if ((rc = grow(g, me.parent, (n_seeds_total + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = grow(g, me.rows, n_pairs * 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = grow(g, me.table, (size_t)world * n_pairs * 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(me.ctx, me.ctx->uf_size, (n_seeds_total + 1) * sizeof(uint32_t)))) return gfail(g, rc, "out of memory");
+    uint32_t *parent = (uint32_t *)me.parent.p;
+    G_HIP(g, uf_init(s, parent, (uint32_t *)me.ctx->uf_size.p, n_seeds_total + 1));
+    G_HIP(g, block_union_pixels(s, b.d_labels, (int)h, (int)w, (int)lo, (int)field_h, parent, (int)clo, (int)field_w));
+    G_HIP(g, block_colour_roots2d(s, b.d_labels, (int)h, (int)w, parent, (uint2 *)me.rows.p, n_pairs));
+    if ((rc = x.gather((const uint32_t *)me.rows.p, n_pairs * 2, (uint32_t *)me.table.p))) return rc;
+    ++rounds;
+    G_HIP(g, union_edges(s, (const uint2 *)me.table.p, (size_t)world * n_pairs, parent, nullptr, nullptr));
+    G_HIP(g, relabel_final_u32(s, b.d_labels, parent, n_seeds_total + 1, b.d_labels, n));      // elementwise: in place
   }
   G_HIP(g, hipStreamSynchronize(s));
   if (rounds_out) *rounds_out = rounds;
@@ -636,14 +656,15 @@ int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows, siz
   return rc;
 }
 
-int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, const ws_tile_block2d *blocks, const ws_options *opt,
-                              uint32_t *exchange_rounds) {
+int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total, const ws_tile_block2d *blocks,
+                              const ws_options *opt, int merging, uint32_t *exchange_rounds) {
   int rc = check_group_call(g, opt);
   if (rc) return rc;
   if (!blocks) return gfail(g, WS_ERR_BAD_ARG, "blocks pointer is null");
   if (py < 1 || px < 1 || py * px != g->world) return gfail(g, WS_ERR_BAD_ARG, "py * px must be the group's number of ranks");
   if (opt->edge_correction) return gfail(g, WS_ERR_UNSUPPORTED, "ws_segment_tiled2d_device takes the field as it is: pad it first");
   if (field_h < (size_t)py || field_w < (size_t)px) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row and one column per tile");
+  if (n_seeds_total >= 0x7FFFFFFFull) return gfail(g, WS_ERR_TOO_LARGE, "colours must stay below 2^31");
   for (size_t i = 0; i < g->ranks.size(); ++i) {
     const ws_tile_block2d &b = blocks[i];
     size_t rws[4], cls[4];
@@ -655,7 +676,7 @@ int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int p
   std::vector<uint32_t> rounds(g->ranks.size(), 0);
   rc = for_local_ranks(g, [&](Rank &me) {
     const size_t i = (size_t)(me.rank - g->first_local);
-    return tiled2d_rank(g, me, field_h, field_w, py, px, blocks[i], opt, &rounds[i]);
+    return tiled2d_rank(g, me, field_h, field_w, py, px, n_seeds_total, blocks[i], opt, merging, &rounds[i]);
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];
   return rc;
@@ -762,7 +783,7 @@ int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t
 // ... in py x px tiles: every local rank uploads its tile of the (padded) image, takes the seeds that fall on its plane with
 // their colours (index + 1), runs tiled2d_rank and writes the rectangle it owns of out_labels.
 int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc, size_t n_seeds,
-                       const ws_options *opt, int py, int px, uint64_t *out_labels, uint32_t *exchange_rounds) {
+                       const ws_options *opt, int py, int px, int merging, uint64_t *out_labels, uint32_t *exchange_rounds) {
   int rc = check_group_call(g, opt);
   if (rc) return rc;
   if ((!img && h * w) || (!seeds_rc && n_seeds) || stride < w) return gfail(g, WS_ERR_BAD_ARG, "bad argument");
@@ -814,7 +835,7 @@ int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size
     b.n_seeds = ns;
     b.d_labels = (uint32_t *)me.labels.p;
     const size_t i = (size_t)(me.rank - g->first_local);
-    if ((rc2 = tiled2d_rank(g, me, ph, pw, py, px, b, &plain, &rounds[i]))) return rc2;
+    if ((rc2 = tiled2d_rank(g, me, ph, pw, py, px, n_seeds, b, &plain, merging, &rounds[i]))) return rc2;
     // ---- the rectangle it owns, widened, into the caller's plane
     const size_t oh = r1 - r0, ow = c1 - c0;
     if (oh * ow) {

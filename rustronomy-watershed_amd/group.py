@@ -152,10 +152,11 @@ class Group:
         torch.cuda.synchronize()
         return blocks, spans, keep
 
-    def segment_tiled2d_device(self, field_h, field_w, py, px, blocks, max_level=254):
+    def segment_tiled2d_device(self, field_h, field_w, py, px, blocks, max_level=254, n_seeds_total=0, merging=False):
         opt = _ffi.Options(max_level)
         rounds = ctypes.c_uint32(0)
-        self._check(_ffi.lib().ws_segment_tiled2d_device(self._h, field_h, field_w, py, px, blocks, ctypes.byref(opt), ctypes.byref(rounds)), "ws_segment_tiled2d_device")
+        self._check(_ffi.lib().ws_segment_tiled2d_device(self._h, field_h, field_w, py, px, n_seeds_total, blocks, ctypes.byref(opt), int(merging),
+                                                         ctypes.byref(rounds)), "ws_segment_tiled2d_device")
         return rounds.value
 
     # ---- a batch of independent slices ------------------------------------------------------------------------------------------

@@ -264,15 +264,20 @@ static int group_sequence_checks() {
     ws_options o2;
     ws_options_default(&o2);
     uint32_t r2 = 0;
-    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, out.data(), &r2) == WS_OK);
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, 0, out.data(), &r2) == WS_OK);
     CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 0, want.data(), nullptr) == 0);
     CHECK(out == want && r2 >= 2);
     o2.edge_correction = 1;
     std::vector<uint64_t> oute((H + 2) * (W + 2)), wante((H + 2) * (W + 2));
-    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, oute.data(), nullptr) == WS_OK);
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, 0, oute.data(), nullptr) == WS_OK);
     CHECK(ws_or_segment_arrival(img.data(), H, W, rc_pairs.data(), n, 254, 1, wante.data(), nullptr) == 0);
     CHECK(oute == wante);
-    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 3, 2, oute.data(), nullptr) == WS_ERR_BAD_ARG);
+    // the merging transform's final labels in tiles, at a level where lakes are not trivial
+    o2.max_water_level = 90;
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 2, 2, 1, oute.data(), nullptr) == WS_OK);
+    CHECK(ws_or_merge_arrival(img.data(), H, W, rc_pairs.data(), n, 90, 1, wante.data(), nullptr, nullptr) == 0);
+    CHECK(oute == wante);
+    CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 3, 2, 0, oute.data(), nullptr) == WS_ERR_BAD_ARG);
     ws_group_destroy(g4);
   }
   const uint64_t bad[2] = {H, 0};

@@ -269,7 +269,7 @@ def test_batch_group_equals_slice_by_slice(pkg):
 
 # ---- 2-D tiles (BASELINE config 5's wording): the field cut in both directions -------------------------------------------------
 
-def _tiled2d(pkg, img, seeds, py, px, max_level=254):
+def _tiled2d(pkg, img, seeds, py, px, max_level=254, merging=False):
     import torch
     grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
     g = grp_mod.Group.local(py * px)
@@ -277,7 +277,7 @@ def _tiled2d(pkg, img, seeds, py, px, max_level=254):
     field = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
     s = torch.from_numpy(np.asarray(seeds, dtype=np.int64).reshape(-1, 2).astype(np.int32)).to(dev)
     blocks, spans, keep = g.make_blocks2d(field, s, py, px)
-    rounds = g.segment_tiled2d_device(img.shape[0], img.shape[1], py, px, blocks, max_level=max_level)
+    rounds = g.segment_tiled2d_device(img.shape[0], img.shape[1], py, px, blocks, max_level=max_level, n_seeds_total=int(s.shape[0]), merging=merging)
     out = np.zeros(img.shape, dtype=np.uint32)
     halo_ok = True
     for (r0, r1, lo, hi), (c0, c1, clo, chi), lab in spans:
@@ -315,6 +315,22 @@ def test_field_in_2d_tiles_equals_the_single_domain_transform(pkg, py, px, kind)
     assert halo_ok and rounds >= 2
 
 
+@pytest.mark.parametrize("py,px", [(2, 2), (3, 2), (1, 3)])
+@pytest.mark.parametrize("max_level", [254, 120, 60])
+def test_merging_final_labels_in_2d_tiles(pkg, py, px, max_level):
+    # lakes that span several tiles, in pieces that are disconnected inside a tile: one gather of (colour, local root) pairs of
+    # every tile's outermost rows and columns joins them (lib.rs:1328-1522 after the last level, against the oracle)
+    img = cases.smooth_field(290, 417, 19, octaves=5)
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    want = ol.merge_arrival(img, seeds, max_level=max_level)
+    got, _, halo_ok = _tiled2d(pkg, img, seeds, py, px, max_level=max_level, merging=True)
+    assert (got == want).all(), (py, px, max_level, int((got != want).sum()))
+    rnd = cases.field(200, 263, 8)
+    rs = np.asarray(ol.find_local_minima(rnd), dtype=np.uint64).reshape(-1, 2)
+    got, _, _ = _tiled2d(pkg, rnd, rs, py, px, max_level=max_level, merging=True)
+    assert (got == ol.merge_arrival(rnd, rs, max_level=max_level)).all()
+
+
 def test_2d_tiles_argument_errors_and_low_levels(pkg):
     import torch
     grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
@@ -344,7 +360,7 @@ def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
     want = eng.segment(img, seeds).clone()
     g = grp_mod.Group.local(6)
     blocks, spans, keep = g.make_blocks2d(img, seeds, 2, 3)
-    g.segment_tiled2d_device(2048, 3072, 2, 3, blocks)
+    g.segment_tiled2d_device(2048, 3072, 2, 3, blocks, n_seeds_total=int(seeds.shape[0]))
     for (r0, r1, lo, hi), (c0, c1, clo, chi), lab in spans:
         assert bool((lab[r0 - lo:r1 - lo, c0 - clo:c1 - clo] == want[r0:r1, c0:c1]).all())
     g.close()
@@ -353,6 +369,6 @@ def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
     small = eng.random_field(256, 384, 3)
     ss = eng.find_local_minima(small)
     blocks, spans, keep = g.make_blocks2d(small, ss, 1, 1)
-    g.segment_tiled2d_device(256, 384, 1, 1, blocks)
+    g.segment_tiled2d_device(256, 384, 1, 1, blocks, n_seeds_total=int(ss.shape[0]))
     assert bool((spans[0][2] == eng.segment(small, ss)).all())
     g.close()
