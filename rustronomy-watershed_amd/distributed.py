@@ -295,6 +295,68 @@ def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
     return block.labels[top:bot], rounds
 
 
+# ---- the field cut in both directions (csrc/ws_tiled.hip: tiled2d_rank) ---------------------------------------------------------
+
+def tile_grid(height, width, rank, py, px):
+    """Rows and columns of rank = ty * px + tx: ((r0, r1, lo, hi), (c0, c1, clo, chi)) -- row_block in each direction."""
+    return row_block(height, rank // px, py), row_block(width, rank % px, px)
+
+
+def local_seeds2d(seeds, lo, hi, clo, chi):
+    """The seeds on a tile's plane (halo ring included), local coordinates, with their colours (index + 1, lib.rs:1670-1672)."""
+    seeds = torch.as_tensor(seeds).reshape(-1, 2)
+    inside = (seeds[:, 0] >= lo) & (seeds[:, 0] < hi) & (seeds[:, 1] >= clo) & (seeds[:, 1] < chi)
+    loc = seeds[inside].clone()
+    loc[:, 0] -= lo
+    loc[:, 1] -= clo
+    return loc, torch.arange(1, seeds.shape[0] + 1, dtype=torch.int64)[inside]
+
+
+def exchange_halos2d(plane, rank, py, px, group=None):
+    """Halo rows AND columns of a tile's plane with its four neighbours, in place (the ring's corner cells are nobody's
+    neighbours in a 4-connected stencil)."""
+    ty, tx = divmod(rank, px)
+    up, down, left, right = ty > 0, ty < py - 1, tx > 0, tx < px - 1
+    h, w = plane.shape
+    dev = _comm_device(plane)
+    ops, recvs = [], []
+
+    def pair(send_view, peer, put):
+        send = send_view.to(dev).contiguous()
+        recv = torch.empty_like(send)
+        ops.extend([dist.P2POp(dist.isend, send, peer, group), dist.P2POp(dist.irecv, recv, peer, group)])
+        recvs.append((put, recv))
+    if up:
+        pair(plane[1], rank - px, lambda r: plane[0].copy_(r))
+    if down:
+        pair(plane[h - 2], rank + px, lambda r: plane[h - 1].copy_(r))
+    if left:
+        pair(plane[:, 1], rank - 1, lambda r: plane[:, 0].copy_(r))
+    if right:
+        pair(plane[:, w - 2], rank + 1, lambda r: plane[:, w - 1].copy_(r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for put, recv in recvs:          # rows first, then columns (the order pair() was called in)
+        put(recv.to(plane.device))
+
+
+def segment_tiled2d(block, rank, py, px, group=None, max_rounds=1 << 20):
+    """Segmenting transform of one field in py x px tiles: the general form's steps on every tile (painted seeds with their
+    global colours, relaxation rounds, label rounds), halo rows and columns swapped after each.  `block`: this rank's engine
+    over its tile plane.  Returns (the labels of the tile's plane, number of collective exchanges)."""
+    block.init()
+    rounds = 0
+    for plane_name, step in (("keys", block.relax), ("labels", block.resolve)):
+        for _ in range(max_rounds):
+            changed = step()
+            exchange_halos2d(getattr(block, plane_name), rank, py, px, group)
+            rounds += 1
+            if not _any_rank(changed, getattr(block, plane_name), group):
+                break
+    return block.labels, rounds
+
+
 def merge_tiled(block, rank, world, row0, field_rows, n_colours_total, group=None):
     """Final canonical labels of the MERGING transform of one field tiled over `world` ranks (lib.rs:1328-1522 after the
     last level: every lake carries the smallest seed colour in it).  `row0`: field row of the block's first LOCAL row

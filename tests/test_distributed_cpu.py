@@ -56,6 +56,48 @@ def _run_tiled(img, seeds, world, max_level=254, force_general=False):
     return np.concatenate(parts, axis=0), rounds[0]
 
 
+def _tiled2d_worker(rank, py, px, port, img, seeds, max_level, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=py * px)
+    try:
+        import importlib
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        from numpy_engine import NumpyBlockEngine
+        (r0, r1, lo, hi), (c0, c1, clo, chi) = wd.tile_grid(img.shape[0], img.shape[1], rank, py, px)
+        loc, col = wd.local_seeds2d(seeds.astype(np.int64), lo, hi, clo, chi)
+        block = NumpyBlockEngine(img[lo:hi, clo:chi], loc.numpy(), col.numpy(), max_level)
+        labels, rounds = wd.segment_tiled2d(block, rank, py, px)
+        np.save(os.path.join(outdir, f"part{rank}.npy"), labels.numpy().view(np.uint32)[r0 - lo:r1 - lo, c0 - clo:c1 - clo])
+        np.save(os.path.join(outdir, f"rounds{rank}.npy"), np.array([rounds]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("py,px", [(2, 2), (1, 3)])
+def test_field_in_2d_tiles_over_gloo_is_bit_exact_with_single_domain(py, px):
+    # the field cut in BOTH directions (csrc/ws_tiled.hip: tiled2d_rank; here distributed.segment_tiled2d over gloo with the
+    # numpy stand-in for the block steps): halo rows and columns, any seed list, every rank in every exchange
+    wd_rows = lambda n, k, parts: (n // parts * k + min(k, n % parts), n // parts * (k + 1) + min(k + 1, n % parts))
+    for img, few in ((cases.field(61, 90, 3), False), (cases.smooth_field(70, 83, 5), True)):
+        seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+        if few:
+            seeds = seeds[:: max(len(seeds) // 3, 1)][:3]
+        else:
+            seeds = seeds[np.random.default_rng(1).permutation(len(seeds))]
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_tiled2d_worker, args=(py, px, _free_port(), img, seeds, 254, d), nprocs=py * px, join=True)
+            got = np.zeros(img.shape, dtype=np.uint32)
+            rounds = set()
+            for rank in range(py * px):
+                (r0, r1), (c0, c1) = wd_rows(img.shape[0], rank // px, py), wd_rows(img.shape[1], rank % px, px)
+                got[r0:r1, c0:c1] = np.load(os.path.join(d, f"part{rank}.npy"))
+                rounds.add(int(np.load(os.path.join(d, f"rounds{rank}.npy"))[0]))
+        assert len(rounds) == 1
+        assert (got == ol.segment_arrival(img, seeds)).all(), (py, px, few)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_tiled_field_is_bit_exact_with_single_domain(world):
     img = cases.field(61, 48, 3)
