@@ -342,6 +342,11 @@ int ws_block_init(ws_ctx *ctx, size_t h, size_t w, const uint32_t *d_seeds_rc, c
 int ws_block_relax(ws_ctx *ctx, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                    uint8_t max_water_level, uint32_t *d_keys, int *changed);
 int ws_block_resolve(ws_ctx *ctx, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w, int *changed);
+/* A tile of a field cut in both directions: the labels of the whole plane from painted labels, in two launches.  Seeds hold
+ * their colours; the plane's border ring holds what is known of the neighbours' pixels so far (0: nothing yet) and is a set
+ * of roots like the seeds.  The caller swaps the ring and repeats until nobody receives anything new (ws_segment_tiled2d*
+ * do). */
+int ws_block_resolve_ring(ws_ctx *ctx, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w);
 
 /* The same block in its fast form, for seed lists in strictly increasing row-major order (what ws_find_local_minima
  * returns): a rank's seeds -- those on any of its local rows, halo rows included -- are then entries [g0, g0 + n) of the

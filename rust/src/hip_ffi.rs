@@ -206,6 +206,7 @@ extern "C" {
         max_water_level: u8, d_keys: *mut u32, changed: *mut c_int) -> c_int;
     pub fn ws_block_resolve(ctx: *mut ws_ctx, d_keys: *const u32, d_labels: *mut u32, h: usize, w: usize,
         changed: *mut c_int) -> c_int;
+    pub fn ws_block_resolve_ring(ctx: *mut ws_ctx, d_keys: *const u32, d_labels: *mut u32, h: usize, w: usize) -> c_int;
     // ... fast form for strictly increasing seed lists: one table exchange for the labels instead of rounds
     pub fn ws_block_begin(ctx: *mut ws_ctx, d_img: *const u8, h: usize, w: usize, row_stride: usize, max_water_level: u8,
         d_seeds_rc: *const u32, n_seeds: usize, first_colour: u32, d_keys: *mut u32) -> c_int;

@@ -132,6 +132,7 @@ SIGNATURES = {
     "ws_block_init": (ctypes.c_int, [vp, sz, sz, vp, vp, sz, vp, vp]),
     "ws_block_relax": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint8, vp, ctypes.POINTER(ctypes.c_int)]),
     "ws_block_resolve": (ctypes.c_int, [vp, vp, vp, sz, sz, ctypes.POINTER(ctypes.c_int)]),
+    "ws_block_resolve_ring": (ctypes.c_int, [vp, vp, vp, sz, sz]),
     "ws_block_begin": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint8, vp, sz, ctypes.c_uint32, vp]),
     "ws_block_relax_halo": (ctypes.c_int, [vp, vp, sz, sz, sz, ctypes.c_uint8, ctypes.c_int, ctypes.c_int, vp]),
     "ws_block_resolve_local": (ctypes.c_int, [vp, vp, vp, sz, sz, ctypes.c_int, ctypes.c_int]),

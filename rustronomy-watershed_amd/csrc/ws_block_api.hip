@@ -89,6 +89,30 @@ int ws_block_resolve(ws_ctx *c, const uint32_t *d_keys, uint32_t *d_labels, size
   return WS_OK;
 }
 
+// A TILE of a field cut in both directions (ws_segment_tiled2d*): labels of the whole plane in two launches from painted
+// labels -- seeds hold their colours, the plane's border ring holds what is known of the neighbours' pixels so far (0:
+// nothing yet) and is a set of roots like the seeds.  Repeated after every swap of the ring until no rank receives anything
+// new: a round carries labels across one tile boundary, against one HOP per launch of the iterative form
+// (8192^2 in 2 x 2 tiles: 32 launches of k_resolve per rank and step, 1.2 of its 2.4 ms).
+int ws_block_resolve_ring(ws_ctx *c, const uint32_t *d_keys, uint32_t *d_labels, size_t h, size_t w) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c || (h * w && (!d_keys || !d_labels))) return fail(c, WS_ERR_BAD_ARG, "bad argument");
+  if (h > 0x7FFFFFF0ull || w > 0x7FFFFFF0ull || h * w >= 0x80000000ull) return fail(c, WS_ERR_TOO_LARGE, "plane has >= 2^31 pixels");
+  if (h * w == 0) return WS_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->refs, resolve_ref_capacity((int)h, (int)w) * sizeof(uint32_t)))) return rc;
+  uint32_t *flags = (uint32_t *)c->flags.p;
+  HIP_TRY(c, hipMemsetAsync(flags + FLAG_OVERFLOW, 0, sizeof(uint32_t), c->stream));
+  c->misc_clean = false;
+  HIP_TRY(c, resolve_two_launch(c->stream, d_keys, d_labels, (int)h, (int)w, (uint32_t *)c->refs.p, c->debug_max_iters, nullptr, nullptr,
+                                nullptr, nullptr, 0, flags + FLAG_OVERFLOW, nullptr, 4));
+  HIP_TRY(c, hipMemcpyAsync(&c->pinned[FLAG_OVERFLOW], flags + FLAG_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pinned[FLAG_OVERFLOW]) return fail(c, WS_ERR_RING_OVERFLOW, "more than 2^24-1 flood rings inside one level");
+  return WS_OK;
+}
+
 // ---- row blocks, fast form: seed side tables, speculative passes, two-launch resolve, one table exchange -------------
 //
 // The same block as above, for seed lists in strictly increasing order (what find_local_minima returns; a rank's seeds

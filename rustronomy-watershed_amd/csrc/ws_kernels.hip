@@ -1295,7 +1295,13 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   if (n == 0) return hipSuccess;
   const size_t nregions = (size_t)tx * ty * (NTHREADS / 64);
   uint32_t *ref_count = ref_scratch, *ref_list = ref_scratch + nregions;
-  if (seed_mask && halo_flags)
+  // halo_flags 4 (a tile of a field cut in both directions, painted labels): the plane's border RING holds other ranks' pixels
+  // with whatever label is known of them so far -- not flooded here (the BLOCK masks), roots like seeds; chains end there
+  const bool ring = !seed_mask && (halo_flags & 4) != 0;
+  halo_flags &= 3;
+  if (ring)
+    k_resolve_local<false, false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, nullptr, nullptr, nullptr, gate, sh, carry_flag, nullptr, 0);
+  else if (seed_mask && halo_flags)
     k_resolve_local<true, false, true><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, nullptr, gate, sh, carry_flag, seed_err, halo_flags);
   else if (seed_mask && tile_min)
     k_resolve_local<true, true, false><<<tx * ty, NTHREADS, 0, s>>>(keys, labels, h, w, tx, ref_count, ref_list, max_rounds, seed_mask, word_base, tile_min, gate, sh, carry_flag, seed_err, 0);
@@ -1309,7 +1315,7 @@ hipError_t resolve_two_launch(hipStream_t s, const uint32_t *keys, uint32_t *lab
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)std::min<size_t>(((nregions + CH_R - 1) / CH_R + 3) / 4, 4096);
   const size_t from = (halo_flags & 1) ? (size_t)w : 0, to = (halo_flags & 2) ? n - (size_t)w : n;
-  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to, h, w, tx, (uint32_t)(tx * ty), halo_flags == 0 ? 1 : 0);
+  k_resolve_chase<<<grid, 256, 0, s>>>(labels, ref_count, ref_list, nregions, n, gate, seed_mask ? seed_err : nullptr, from, to, h, w, tx, (uint32_t)(tx * ty), halo_flags == 0 && !ring ? 1 : 0);
   return hipGetLastError();
 }
 

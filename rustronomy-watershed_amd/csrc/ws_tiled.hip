@@ -382,21 +382,59 @@ int tiled2d_rank(ws_group *g, Rank &me, size_t field_h, size_t field_w, int py, 
   uint32_t *keys = (uint32_t *)me.keys.p, *recv = (uint32_t *)me.recv.p;
   hipStream_t s = me.ctx->stream;
   G_WS(g, me, ws_block_init(me.ctx, h, w, b.d_seeds_rc, b.d_colours, b.n_seeds, keys, b.d_labels));
-  for (int phase = 0; phase < 2; ++phase) {
-    uint32_t *plane = phase == 0 ? keys : b.d_labels;
-    for (;;) {
+  auto copy_ring_in = [&](uint32_t *plane) -> int {
+    if (nb[0] >= 0) G_HIP(g, hipMemcpyAsync(plane, recv, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (nb[1] >= 0) G_HIP(g, hipMemcpyAsync(plane + (h - 1) * w, recv + w, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    // (columns after rows: a halo column's first / last cell is a corner of the ring, read by nobody)
+    G_HIP(g, block_unpack_cols(s, plane, h, w, nb[2] >= 0 ? recv + 2 * w : nullptr, nb[3] >= 0 ? recv + 2 * w + h : nullptr));
+    return WS_OK;
+  };
+  // stamps: relax to local convergence, swap the ring, until no rank changed anything
+  for (;;) {
+    int changed = 0;
+    G_WS(g, me, ws_block_relax(me.ctx, b.d_img, h, w, b.img_stride, opt->max_water_level, keys, &changed));
+    if ((rc = x.swap2d(keys, h, w, nb))) return rc;
+    if ((rc = copy_ring_in(keys))) return rc;
+    uint32_t any = 0;
+    if ((rc = x.reduce_host(changed ? 1u : 0u, true, &any))) return rc;
+    ++rounds;
+    if (!any) break;
+  }
+  // labels: the whole tile in two launches from its seeds and from what the ring says so far (ws_block_resolve_ring), swap
+  // the ring, until no rank receives a ring that differs from the one it holds: a round carries labels across one tile
+  // boundary.  (The iterative resolve -- one hop per launch -- took 32 launches per rank where this takes 3 rounds of 2.)
+  if (n >= 0x80000000ull) {
+    for (;;) {      // planes of 2^31 pixels and more: the iterative form
       int changed = 0;
-      if (phase == 0) G_WS(g, me, ws_block_relax(me.ctx, b.d_img, h, w, b.img_stride, opt->max_water_level, keys, &changed));
-      else G_WS(g, me, ws_block_resolve(me.ctx, keys, b.d_labels, h, w, &changed));
-      if ((rc = x.swap2d(plane, h, w, nb))) return rc;
-      if (nb[0] >= 0) G_HIP(g, hipMemcpyAsync(plane, recv, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-      if (nb[1] >= 0) G_HIP(g, hipMemcpyAsync(plane + (h - 1) * w, recv + w, w * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-      // (columns after rows: a halo column's first / last cell is a corner of the ring, read by nobody)
-      G_HIP(g, block_unpack_cols(s, plane, h, w, nb[2] >= 0 ? recv + 2 * w : nullptr, nb[3] >= 0 ? recv + 2 * w + h : nullptr));
+      G_WS(g, me, ws_block_resolve(me.ctx, keys, b.d_labels, h, w, &changed));
+      if ((rc = x.swap2d(b.d_labels, h, w, nb))) return rc;
+      if ((rc = copy_ring_in(b.d_labels))) return rc;
       uint32_t any = 0;
       if ((rc = x.reduce_host(changed ? 1u : 0u, true, &any))) return rc;
       ++rounds;
       if (!any) break;
+    }
+  } else {
+    if ((rc = grow(g, me.rows, (2 * h + 1) * sizeof(uint32_t)))) return rc;
+    uint32_t *held = (uint32_t *)me.rows.p;      // the halo columns I hold, packed like the received ones
+    for (;;) {
+      G_WS(g, me, ws_block_resolve_ring(me.ctx, keys, b.d_labels, h, w));
+      if ((rc = x.swap2d(b.d_labels, h, w, nb))) return rc;
+      G_HIP(g, hipMemsetAsync(me.flag, 0, sizeof(uint32_t), s));
+      // (the four corner cells of the ring are left out: the row copy and the column copy both write them, with different
+      // ranks' values, and nobody's stencil reads them)
+      if (nb[0] >= 0 && w > 2) G_HIP(g, block_rows_differ(s, recv + 1, b.d_labels + 1, w - 2, me.flag));
+      if (nb[1] >= 0 && w > 2) G_HIP(g, block_rows_differ(s, recv + w + 1, b.d_labels + (h - 1) * w + 1, w - 2, me.flag));
+      if (nb[2] >= 0 || nb[3] >= 0) {
+        G_HIP(g, block_pack_cols(s, b.d_labels, h, w, 0, w - 1, held));
+        if (nb[2] >= 0 && h > 2) G_HIP(g, block_rows_differ(s, recv + 2 * w + 1, held + 1, h - 2, me.flag));
+        if (nb[3] >= 0 && h > 2) G_HIP(g, block_rows_differ(s, recv + 2 * w + h + 1, held + h + 1, h - 2, me.flag));
+      }
+      uint32_t any = 0;
+      if ((rc = x.reduce(true, &any))) return rc;
+      ++rounds;
+      if (!any) break;
+      if ((rc = copy_ring_in(b.d_labels))) return rc;
     }
   }
   if (merging) {
