@@ -169,7 +169,7 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
  * every mode.  1: first come, first served (a ring).  2: in flood order -- 31 buckets by the level of the smallest stamp that
  * waits at a tile's borders, the lowest non-empty bucket first, and a run that announces a tile of its own bucket takes it
  * itself; it runs on 128 x 128 tiles and starts at pass 3.  0: the ordinary passes.  3 (the default): mode 2 when the seeds
- * are sparse -- fewer than one per 64 tiles, so that every flood crosses many tiles -- the passes otherwise.  Measured on
+ * are sparse -- fewer than one per two tiles, so that floods cross several tiles each -- the passes otherwise.  Measured on
  * 8192^2 smooth maps of correlation length 4 / 16 / 64 / 256 px (683 k / 8.6 k / 35 / 1 seeds): 3.0 / 5.8 / 6.7 / 3.5 ms with the
  * passes, 3.0 / 6.4 / 6.4 / 4.1 with mode 1, 4.2 / 5.8 / 3.9 / 3.2 with mode 2, 3.0 / 5.8 / 3.9 / 3.2 with the default
  * (profiles/r3_v1_persistent_ab.txt).  Transforms that converge in a few passes (random fields) never

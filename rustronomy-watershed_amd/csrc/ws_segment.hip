@@ -43,13 +43,15 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   c->graph_sufficed = false;
 
   // The late passes of a long-range flood as one queue launch in flood order (relax_pass, ws_ctx_set_persistent_pass)?  Auto:
-  // when the seeds are sparse -- fewer than one per 64 of the 128 x 64 tiles, so every flood crosses many tiles.
-  // 8192^2 smooth maps: 35 seeds 6.9 -> 3.9 ms, one seed 3.6 -> 3.2 ms; 683 k and 8.6 k seeds (3.0 / 5.8 ms) stay with the passes.
+  // when the seeds are sparse -- fewer than one per two of the 128 x 64 tiles, so that floods cross several tiles each.
+  // 8192^2 smooth maps, correlation length 20 / 24 / 32 / 48 / 64 / 256 px (3.6 k / 1.7 k / 565 / 107 / 35 / 1 seeds), two draws
+  // each: 6.1-6.3 -> 5.3-5.7, 6.6-7.5 -> 5.0-5.6, 8.7 -> 5.7-6.1, 8.4-8.9 -> 5.8-7.3, 6.9 -> 3.9, 3.6 -> 3.0 ms; at 16 px (8.6 k
+  // seeds, one per tile) a draw, at 12 px and below (26 k seeds and more) the passes win (tools/exp_auto_check.py).
   // (seeds from the image's own minima: their number is only known afterwards -- the count of the context's previous such
   // transform stands in for it, a prediction like expect_sorted; a wrong one costs time, not labels)
   const size_t n_for_auto = minima ? c->minima_found_before : n_seeds;
   const int persist_mode = c->persistent_pass != 3 ? c->persistent_pass
-                                                   : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) / 64 ? 2 : 0);
+                                                   : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) / 2 ? 2 : 0);
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
   // are free to change: a pipeline that reuses its buffers) replays its optimistic part -- seed tables, the first

@@ -69,7 +69,7 @@ def _sparse_smooth_case():      # (one field, one oracle run for the three modes
 @pytest.mark.parametrize("mode", [3, 2, 1])
 def test_sparse_seeds_on_a_smooth_map_take_the_tile_queue_and_equal_the_oracle(pkg, mode):
     # Long-range floods: a smooth 4096^2 map with two dozen seeds.  Auto (3, the default) picks the persistent pass in flood
-    # order (seeds >= 4 and fewer than one per 64 tiles); 2 and 1 force the two queue forms.  Every label against the oracle.
+    # order (fewer seeds than one per two tiles); 2 and 1 force the two queue forms.  Every label against the oracle.
     import ctypes
     import torch
     img, seeds, want = _sparse_smooth_case()

@@ -415,11 +415,15 @@ def test_segment_large_smooth_fields_long_range(pkg, shape, octaves, few_seeds):
     if few_seeds:
         seeds = seeds[:: max(len(seeds) // 5, 1)][:5]
     ws = _seg(pkg, pkg.ENGINE_FUSED)
+    set_mode = pkg._ffi.lib().ws_ctx_set_persistent_pass
+    assert set_mode(ws._ctx().handle, 0) == 0      # the passes themselves (with sparse seeds the default takes the tile queue)
     got = ws.transform(img, seeds)
+    assert set_mode(ws._ctx().handle, 3) == 0
     want = ol.segment_arrival(img, seeds)
     assert got.shape == want.shape and (got == want).all()
     st = ws._ctx().stats()
     assert st["relax_passes"] >= 8           # the scan-capable kernel variant ran (passes >= 4)
+    assert (ws.transform(img, seeds) == want).all()      # ... and whatever the default picks
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -578,12 +582,18 @@ def test_graph_replay_of_repeated_transforms(pkg):
         d_one.copy_(torch.from_numpy(lists[3]).to(torch.int32))
         d_img.copy_(torch.from_numpy(maze))
         replays = 0
+        set_mode = pkg._ffi.lib().ws_ctx_set_persistent_pass
+        assert set_mode(eng.ctx.handle, 0) == 0      # (the passes: with one seed the default would end inside the graph, through the tile queue)
         for rep in range(4):
             got = eng.segment(d_img, d_one, out=out).cpu().numpy().view(np.uint32)
             replays += eng.stats()["graph_launches"]
             assert eng.stats()["relax_passes"] > 8
             assert (got == ol.segment_arrival(maze, lists[3])).all(), rep
         assert replays >= 2, replays
+        assert set_mode(eng.ctx.handle, 3) == 0
+        for rep in range(3):                         # ... and the default: the queue inside the replayed graph
+            got = eng.segment(d_img, d_one, out=out).cpu().numpy().view(np.uint32)
+            assert (got == ol.segment_arrival(maze, lists[3])).all(), rep
         # merging and batches repeat as well (their own keys)
         d_img.copy_(torch.from_numpy(imgs[0]))
         d_seeds.copy_(torch.from_numpy(lists[0][:n]).to(torch.int32))
@@ -601,11 +611,16 @@ def test_graph_replay_of_repeated_transforms(pkg):
             m = eng.merge(d_img, d_seeds, out=mout).cpu().numpy().view(np.uint32)
             assert (m == ol.merge_arrival(imgs[k], lists[k][:n])).all(), rep
         d_img.copy_(torch.from_numpy(maze))
+        assert set_mode(eng.ctx.handle, 0) == 0      # (as above: the passes, so that the flood outlasts the graph)
         for rep in range(4):
             m = eng.merge(d_img, d_one, out=mout).cpu().numpy().view(np.uint32)
             assert eng.stats()["relax_passes"] > 8
             assert (m == ol.merge_arrival(maze, lists[3])).all(), rep
         assert eng.stats()["graph_launches"] == 1
+        assert set_mode(eng.ctx.handle, 3) == 0
+        for rep in range(3):
+            m = eng.merge(d_img, d_one, out=mout).cpu().numpy().view(np.uint32)
+            assert (m == ol.merge_arrival(maze, lists[3])).all(), rep
         himgs, hseeds = _batch_case(4, 32, 64, 900)
         offs = np.concatenate([[0], np.cumsum([len(x) for x in hseeds])])
         cube = torch.from_numpy(np.stack(himgs)).to(eng.device)
@@ -737,7 +752,7 @@ def test_long_range_stacked_slices(pkg):
 
 
 def test_sparse_seeds_take_the_tile_queue_in_stacks_low_levels_and_merging(pkg):
-    # The default picks the persistent pass in flood order when seeds are sparse (fewer than one per 64 tiles).  Here: a stack
+    # The default picks the persistent pass in flood order when seeds are sparse (fewer than one per two tiles).  Here: a stack
     # of two smooth slices (slice walls inside the queue's 128 x 128 tiles), a low maximum level (few buckets: the queue's
     # order has one or two levels per bucket, and most of the plane is never flooded), an odd-sized plane, the merging
     # transform's final labels -- every label against the oracle.
