@@ -172,8 +172,9 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
  * are sparse -- fewer than one per two tiles, so that floods cross several tiles each -- the passes otherwise.  Measured on
  * 8192^2 smooth maps of correlation length 4 / 16 / 64 / 256 px (683 k / 8.6 k / 35 / 1 seeds): 3.0 / 5.8 / 6.7 / 3.5 ms with the
  * passes, 3.0 / 6.4 / 6.4 / 4.1 with mode 1, 4.2 / 5.8 / 3.9 / 3.2 with mode 2, 3.0 / 5.8 / 3.9 / 3.2 with the default
- * (profiles/r3_v1_persistent_ab.txt).  Transforms that converge in a few passes (random fields) never
- * reach that pass.  WS_ERR_BAD_ARG for any other mode. */
+ * (profiles/r3_v1_persistent_ab.txt).  4: the passes on their EARLY schedule (one grid from pass 3,
+ * scans from pass 2), what the default picks for between one seed per two tiles and ~30 per tile (5.8 -> 5.3 ms at 16 px).
+ * Transforms that converge in a few passes (random fields) never reach those passes.  WS_ERR_BAD_ARG for any other mode. */
 int ws_ctx_set_persistent_pass(ws_ctx *ctx, int mode);
 /* The merging transform_to_list of a seed list with at least this many entries writes every level's lake records from the
  * list of the lakes alive at the level before, instead of looking at every colour at every level (same records, the order

@@ -282,7 +282,7 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *c, size_t min_px) {
 
 int ws_ctx_set_persistent_pass(ws_ctx *c, int mode) {
   if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
-  if (!c || mode < 0 || mode > 3) return WS_ERR_BAD_ARG;
+  if (!c || mode < 0 || mode > 4) return WS_ERR_BAD_ARG;
   c->persistent_pass = mode;
   ++c->buffer_generation;      // a captured graph holds the launches of the other form
   return WS_OK;

@@ -1506,7 +1506,11 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   const int persist_mode = tuning_env("WS_RELAX_PERSIST") ? atoi(tuning_env("WS_RELAX_PERSIST")) : persistent_pass;      // (A/B knob, tools/ only)
   const bool queue_plane = persist_mode == 2 && tile_list && !pad && (w & 3) == 0 && w >= RX_P &&
                            ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && relax_tiles(h, w) < (1u << 24);
-  const bool early_queue = queue_plane && queue_from < same_from_passes;
+  // ... and so do the passes themselves on maps of middling seed density (persist_mode 4: the caller has seen between one
+  // seed per two tiles and ~30 per tile): same grid from pass 3, scans from pass 2, lists from pass 3.  8192^2 smooth maps,
+  // correlation 6 / 8 / 10 / 12 / 16 px: 3.45 / 3.79 / 4.37 / 4.68 / 5.76 -> 3.37 / 3.59 / 4.13 / 4.38 / 5.26 ms; at 4 px
+  // (80 seeds per tile) the late schedule wins, 2.96 against 3.12, and a random field never gets that far (gpurun_out/r3ax, r3ay).
+  const bool early_queue = (queue_plane || (persist_mode == 4 && tile_list)) && queue_from < same_from_passes;
   const uint32_t same_from = early_queue ? queue_from : same_from_passes;
   const int read_same = pass >= same_from ? 1 : 0, write_same = pass + 1 >= same_from ? 1 : 0;
   const uint32_t list_cap = (uint32_t)relax_tiles(h, w);      // entries per tile list
@@ -1639,7 +1643,7 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
         // flags of a pass); in flood order (mode 2, from pass 3, on 128 x 128 tiles) 4.2 / 5.8 / 3.9 / 3.0: a third of the
         // tile runs, and a win where floods are long.  The context picks mode 2 by itself when seeds are sparse
         // (run_fused_form); ws_ctx_set_persistent_pass forces or forbids.
-        const bool persist = persist_mode != 0 && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
+        const bool persist = (persist_mode == 1 || persist_mode == 2) && split && pass == same_from && !pad && (w & 3) == 0 && w >= RX_P &&
                              ((reinterpret_cast<uintptr_t>(img) | img_stride) & 3u) == 0 && (size_t)gx * gy <= list_cap && list_cap < (1u << 24);
         if (persist) {
           const bool in_order = persist_mode == 2;      // buckets in flood order (PERSIST == 2) instead of the first-come ring

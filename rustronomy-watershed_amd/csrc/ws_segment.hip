@@ -51,7 +51,8 @@ int run_fused_form(ws_ctx *c, const uint8_t *d_img, size_t stride, int ph, int p
   // transform stands in for it, a prediction like expect_sorted; a wrong one costs time, not labels)
   const size_t n_for_auto = minima ? c->minima_found_before : n_seeds;
   const int persist_mode = c->persistent_pass != 3 ? c->persistent_pass
-                                                   : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) / 2 ? 2 : 0);
+                                                   : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) / 2 ? 2
+                                                      : (n_for_auto >= 1 && n_for_auto <= relax_tiles(ph, pw) * 32 ? 4 : 0));      // (4: the passes, on the early schedule)
   // ---- graph replay -------------------------------------------------------------------------------
   // A transform that repeats the previous one's arguments exactly (same buffers, sizes and seed COUNT; the contents
   // are free to change: a pipeline that reuses its buffers) replays its optimistic part -- seed tables, the first
