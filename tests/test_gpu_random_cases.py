@@ -272,3 +272,41 @@ def test_random_transform_to_list_bit_exact():
         assert [l for l, _ in got] == list(range(max_level + 1)), (case, merging)
         for (lvl, hist), wnt in zip(got, want):
             assert hist.shape == wnt.shape and (hist == wnt).all(), (case, lvl, h, w, merging, edge, max_level)
+
+
+def test_random_smooth_maps_across_the_three_schedules():
+    """Smooth fields of random shape and correlation with seed lists thinned at random: the default's three regimes by seeds
+    per tile -- the tile queue in flood order, the passes on the early schedule, the passes as they were -- each also
+    forced (modes 2, 4, 0), on ONE context so that captured graphs of one mode meet transforms of another; segmenting and,
+    now and then, the merging transform's final labels, against the arrival-form oracle."""
+    import cases
+    ge.build_hip()
+    pkg = ge.load_package()
+    rng = np.random.default_rng(4242 + int(os.environ.get("WS_TEST_SEED_OFFSET", "0")))
+    ws = pkg.TransformBuilder.new().set_engine(pkg.ENGINE_FUSED).build_segmenting()
+    set_mode = pkg._ffi.lib().ws_ctx_set_persistent_pass
+    picked = {0: 0, 2: 0, 4: 0}
+    for case in range(24):
+        h = int(rng.integers(300, 1400))
+        w = int(rng.integers(80, 400)) * 4 if case % 5 else int(rng.integers(300, 1500))      # now and then a width that is no multiple of 4
+        img = cases.smooth_field(h, w, int(rng.integers(1, 1000)), octaves=int(rng.integers(4, 8)))
+        seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+        keep = int(rng.choice([1, 3, 12, 60, 400]))
+        seeds = seeds[:: keep] if len(seeds) > keep else seeds
+        if len(seeds) == 0:
+            continue
+        max_level = int(rng.choice([254, 254, 160, 70]))
+        want = ol.segment_arrival(img, seeds, max_level=max_level)
+        b = pkg.TransformBuilder.new().set_engine(pkg.ENGINE_FUSED).set_max_water_lvl(max_level)
+        ws = b.build_segmenting()
+        for mode in (3, int(rng.choice([0, 2, 4]))):
+            assert set_mode(ws._ctx().handle, mode) == 0
+            got = ws.transform(img, seeds)
+            assert (got == want).all(), (case, h, w, len(seeds), max_level, mode, int((got != want).sum()))
+        tiles = ((w + 127) // 128 + 1) * ((h + 63) // 64 + 1)
+        picked[2 if len(seeds) * 2 <= tiles else (4 if len(seeds) <= 32 * tiles else 0)] += 1
+        assert set_mode(ws._ctx().handle, 3) == 0
+        if case % 6 == 0:
+            mg = pkg.TransformBuilder.new().set_max_water_lvl(max_level).build_merging()
+            assert (mg.transform_final(img, seeds) == ol.merge_arrival(img, seeds, max_level=max_level)).all(), (case, "merge")
+    assert picked[2] >= 3 and picked[4] >= 3, picked      # (roughly: relax_tiles is a little larger than this count)
