@@ -1546,6 +1546,11 @@ hipError_t relax_pass(hipStream_t s, const uint8_t *img, size_t img_stride, uint
   }();
   const uint32_t scan_from = early_queue ? same_from - 1u : std::max(scan_from_knob, 1u);
   if (pass >= scan_from && late_cap != 0 && late_cap < max_iters) max_iters = late_cap;
+  // (tuning knob, tools/ only: "n,c" -- the first n scan passes with c rounds instead)
+  if (const char *e = tuning_env("WS_RELAX_WIDE_CAP")) {
+    int n_ = 0, c_ = 0;
+    if (sscanf(e, "%d,%d", &n_, &c_) == 2 && pass >= scan_from && pass < scan_from + (uint32_t)n_) max_iters = (uint32_t)c_;
+  }
   // Passes 1 .. 3 have no scans: on a smooth map a tile that iterates to its own fixpoint by sweeps alone takes up to 64
   // rounds to carry a flood across its 256 columns, all 8192 tiles of them, in a pass that the scan passes then redo.
   static const uint32_t early_cap = [] {
