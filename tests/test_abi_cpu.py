@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -166,3 +167,26 @@ def test_integration_extern_block_lists_every_header_function():
     for method in ("fn transform(", "fn transform_with_hook(", "fn transform_to_list(", "fn transform_history(",
                    "fn find_local_minima(", "fn pre_processor_with_max<", "fn build_segmenting(", "fn build_merging("):
         assert method in shim, method
+
+
+def test_bench_and_entry_point_compile_and_parse_their_arguments():
+    # bench.py only runs on a GPU box: here it must at least be importable Python with the contract's flags
+    import importlib.util
+    import py_compile
+    for name in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(ROOT, name), doraise=True)
+    spec = importlib.util.spec_from_file_location("ws_bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["bench.py", "--gpus", "2", "--steps", "7", "--warmup", "3", "--config", "c5", "--tiles", "2x1"]
+    try:
+        a = mod.parse_args()
+    finally:
+        sys.argv = argv
+    assert (a.gpus, a.steps, a.warmup, a.config, a.tiles) == (2, 7, 3, "c5", "2x1")
+    sys.argv = ["bench.py"]
+    try:
+        d = mod.parse_args()
+    finally:
+        sys.argv = argv
+    assert d.gpus == 1 and d.config == "headline" and d.steps >= 1 and d.warmup >= 0
