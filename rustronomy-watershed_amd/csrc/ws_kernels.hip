@@ -1563,11 +1563,13 @@ hipError_t minima_count(hipStream_t s, const uint8_t *img, size_t stride, int h,
 // it has to search and check; here they fall out of the compaction: a group IS a mask word, its place in the list the
 // word's base).  With them the kernel also zeroes the two small arrays that k_seed_tables zeroes for the transform.
 // out_rc may then be null: a transform seeded by the image's own minima needs no list.
+template <bool LIST>
 __global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict__ nibbles, int H, int W,
                                                       const uint32_t *__restrict__ counts, uint32_t *out_rc, size_t cap,
                                                       uint32_t *mask, uint32_t *word_base,
                                                       uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b, uint32_t *total) {
   __shared__ uint32_t s_part[4];
+  __shared__ uint2 s_stage[LIST ? 4 : 1][LIST ? 1024 : 1];      // (32 KiB: a step's list entries per wave; none for the tables alone)
   {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = tid; i < n_zero_a; i += step) zero_a[i] = 0u;
@@ -1605,22 +1607,32 @@ __global__ __launch_bounds__(256) void k_minima_write(const uint8_t *__restrict_
       mask[wi] = word;
       word_base[wi] = (uint32_t)at;
     }
-    if (out_rc) {
+    const uint32_t step_total = (uint32_t)__shfl((int)incl, 63, 64);
+    if (LIST) {
+      // the step's entries through LDS: a lane's own are three or four, 28 bytes from its neighbour's -- written where they
+      // arise, every store instruction touched dozens of lines; staged, the wave writes them 512 contiguous bytes a time
+      // (at most one maximum per 2 x 2 block: 16 a lane, 1024 a step)
+      uint2 *stage = s_stage[threadIdx.x >> 6];
+      uint32_t k = incl - c;
       while (word) {
         const int b = __builtin_ctz(word);
         word &= word - 1u;
-        if (at < cap) *reinterpret_cast<uint2 *>(out_rc + 2 * at) = make_uint2((uint32_t)y, (uint32_t)(g * 32 + b));
-        ++at;
+        stage[k++] = make_uint2((uint32_t)y, (uint32_t)(g * 32 + b));
       }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      for (uint32_t i = (uint32_t)lane; i < step_total; i += 64u)
+        if (pos + i < cap) *reinterpret_cast<uint2 *>(out_rc + 2 * (pos + i)) = stage[i];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the stage is read before the next step fills it
     }
-    pos += (uint32_t)__shfl((int)incl, 63, 64);
+    pos += step_total;
   }
 }
 
 hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, const uint32_t *counts, uint32_t *total, uint32_t *out_rc, size_t cap,
                         uint32_t *mask, uint32_t *word_base, uint32_t *zero_a, size_t n_zero_a, uint32_t *zero_b, size_t n_zero_b) {
   if (h == 0 || w == 0) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
-  k_minima_write<<<(h + 3) / 4, 256, 0, s>>>(nibbles, h, w, counts, out_rc, cap, mask, word_base, zero_a, n_zero_a, zero_b, n_zero_b, total);
+  if (out_rc) k_minima_write<true><<<(h + 3) / 4, 256, 0, s>>>(nibbles, h, w, counts, out_rc, cap, mask, word_base, zero_a, n_zero_a, zero_b, n_zero_b, total);
+  else k_minima_write<false><<<(h + 3) / 4, 256, 0, s>>>(nibbles, h, w, counts, out_rc, cap, mask, word_base, zero_a, n_zero_a, zero_b, n_zero_b, total);
   return hipGetLastError();
 }
 
