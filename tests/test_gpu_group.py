@@ -372,3 +372,17 @@ def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
     g.segment_tiled2d_device(256, 384, 1, 1, blocks, n_seeds_total=int(ss.shape[0]))
     assert bool((spans[0][2] == eng.segment(small, ss)).all())
     g.close()
+
+
+@pytest.mark.parametrize("shape,py,px", [((2, 2), 2, 2), ((4, 4), 2, 2), ((3, 9), 1, 3), ((9, 3), 3, 1), ((5, 7), 2, 3), ((16, 1), 4, 1), ((1, 12), 1, 4), ((40, 33), 3, 2)])
+def test_2d_tiles_of_a_pixel_or_two(pkg, shape, py, px):
+    # tiles whose planes are all halo, single rows and columns, fields smaller than a relaxation tile: segmenting and merging
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = rng.integers(0, 200, shape, dtype=np.uint8)
+    n = max(shape[0] * shape[1] // 5, 1)
+    seeds = np.stack([rng.integers(0, shape[0], n), rng.integers(0, shape[1], n)], axis=1).astype(np.uint64)
+    seeds = np.unique(seeds, axis=0)
+    got, _, halo_ok = _tiled2d(pkg, img, seeds, py, px)
+    assert halo_ok and (got == ol.segment_arrival(img, seeds)).all(), (shape, py, px)
+    got, _, _ = _tiled2d(pkg, img, seeds, py, px, max_level=120, merging=True)
+    assert (got == ol.merge_arrival(img, seeds, max_level=120)).all(), (shape, py, px, "merging")
