@@ -9,7 +9,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 5 --warmup 1 --no-extras > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/bench.py --steps 5 --warmup 3 --no-extras --no-pipeline > $out/kt.log 2>&1
 f=$(find $out/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/tools/pmc_probe.py --steps 3 > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/tools/pmc_probe.py --steps 3 > $out/pmc_write.log 2>&1
