@@ -176,6 +176,12 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
  * scans from pass 2), what the default picks for between one seed per two tiles and ~30 per tile (5.8 -> 5.3 ms at 16 px).
  * Transforms that converge in a few passes (random fields) never reach those passes.  WS_ERR_BAD_ARG for any other mode. */
 int ws_ctx_set_persistent_pass(ws_ctx *ctx, int mode);
+/* Host threads the host-buffer entry points may start for the length of a call (default 4, at most 64, never more than the
+ * machine has): from 2^20 pixels on a u64 label plane (ws_segment, ws_segment_minima, ws_merge ...) crosses the bus as the device's
+ * u32 plane in 16 MiB chunks and these threads widen each chunk into the caller's memory while the next ones are in flight --
+ * half the bytes over PCIe (8192^2: ws_segment_minima 11.5 -> 7.2 ms).  0: no threads, the plane is widened on the device and
+ * copied whole, as before. */
+int ws_ctx_set_host_threads(ws_ctx *ctx, int n_threads);
 /* The merging transform_to_list of a seed list with at least this many entries writes every level's lake records from the
  * list of the lakes alive at the level before, instead of looking at every colour at every level (same records, the order
  * inside a level differs).  0 restores the default, 2^20: fewer colours are bound by launch latency and gain nothing.
@@ -193,14 +199,18 @@ int ws_options_validate(const ws_options *opt);
 int ws_find_local_minima(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
                          uint64_t *out_rc, size_t cap, size_t *n_found);
 
-/* Watershed::transform for SegmentingWatershed (lib.rs:1810-1822, intended semantics). */
+/* Watershed::transform for SegmentingWatershed (lib.rs:1810-1822, intended semantics).
+ * out_labels is the reference's Array2<usize> plane.  From 2^20 pixels on the labels cross the bus as the device's u32 plane, in
+ * chunks, and host threads of the library (ws_ctx_set_host_threads: four; 0 = none, one 8-byte copy) widen them into
+ * out_labels while the next chunks are in flight: 8192^2 9.2 ms instead of 13.7.  The threads live for
+ * the call only. */
 int ws_segment(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
                const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
                uint64_t *out_labels);
 
-/* The same with the labels as the device holds them, uint32_t (colours are 1..=n_seeds < 2^32): half the bytes of the
- * usize plane over PCIe (8192^2: 256 MiB instead of 512 -- the transform itself is 0.56 ms of the 13.7 ms ws_segment takes there,
- * the rest is the link at its 53 GB/s).  For callers that can hold u32 labels; not what transform() returns. */
+/* The same with the labels as the device holds them, uint32_t (colours are 1..=n_seeds < 2^32): one plain copy, no host
+ * threads, half the bytes in the caller's memory (8192^2: 8.7 ms; the transform itself is 0.56 ms of it, the rest is the link at
+ * its 53 GB/s).  For callers that can hold u32 labels; not what transform() returns. */
 int ws_segment_u32(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, size_t row_stride,
                    const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt,
                    uint32_t *out_labels);

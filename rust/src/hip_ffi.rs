@@ -143,6 +143,7 @@ extern "C" {
     pub fn ws_ctx_set_seam_repair_min_pixels(ctx: *mut ws_ctx, min_px: usize) -> c_int;
     pub fn ws_ctx_set_live_list_min_colours(ctx: *mut ws_ctx, min_colours: usize) -> c_int;
     pub fn ws_ctx_set_persistent_pass(ctx: *mut ws_ctx, mode: c_int) -> c_int;
+    pub fn ws_ctx_set_host_threads(ctx: *mut ws_ctx, n_threads: c_int) -> c_int;
     pub fn ws_options_default(out: *mut ws_options) -> c_int;
     pub fn ws_options_validate(opt: *const ws_options) -> c_int;
 

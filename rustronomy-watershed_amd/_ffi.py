@@ -100,6 +100,7 @@ SIGNATURES = {
     "ws_ctx_set_seam_repair_min_pixels": (ctypes.c_int, [vp, sz]),
     "ws_ctx_set_live_list_min_colours": (ctypes.c_int, [vp, sz]),
     "ws_ctx_set_persistent_pass": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ws_ctx_set_host_threads": (ctypes.c_int, [vp, ctypes.c_int]),
     "ws_options_default": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_options_validate": (ctypes.c_int, [ctypes.POINTER(Options)]),
     "ws_find_local_minima": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),

@@ -237,6 +237,7 @@ void ws_ctx_destroy(ws_ctx *c) {
                     &c->uf_parent, &c->uf_size, &c->uf_hooked, &c->uf_death, &c->uf_sd, &c->alive, &c->px_items, &c->edge_items, &c->mflags, &c->lakes, &c->refs, &c->seed_tab, &c->tile_list})
     if (b->p) (void)hipFree(b->p);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  host_copy_release(c);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   for (hipGraphExec_t g : c->list_graphs) if (g) (void)hipGraphExecDestroy(g);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -285,6 +286,13 @@ int ws_ctx_set_persistent_pass(ws_ctx *c, int mode) {
   if (!c || mode < 0 || mode > 4) return WS_ERR_BAD_ARG;
   c->persistent_pass = mode;
   ++c->buffer_generation;      // a captured graph holds the launches of the other form
+  return WS_OK;
+}
+
+int ws_ctx_set_host_threads(ws_ctx *c, int n_threads) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c || n_threads < 0 || n_threads > 64) return WS_ERR_BAD_ARG;
+  c->host_threads = n_threads;
   return WS_OK;
 }
 

@@ -61,6 +61,9 @@ struct ws_ctx {
   size_t ev_used = 0;
   std::vector<wsapi::TimedSpan> spans;
   std::vector<uint64_t> host64;    // hook staging
+  uint32_t *hc_stage = nullptr;    // ws_hostcopy.hip: pinned staging slots of the chunked label copy (made on first use)
+  hipEvent_t hc_ev[4]{};           // one per slot: its copy has landed
+  int host_threads = 4;            // ... and the threads that widen the chunks (ws_ctx_set_host_threads; 0: one 8-byte copy instead)
   std::vector<uint8_t> host_img;
   size_t last_h = 0, last_w = 0;
   bool have_keys = false;
@@ -174,6 +177,11 @@ struct Span {
 
 void stats_begin(ws_ctx *c);
 int stats_end(ws_ctx *c);
+// ws_hostcopy.hip: the device's u32 labels into a host caller's u64 plane, 4 bytes a pixel over the bus, widened by host threads
+// while the next chunks are in flight; returns with the copy complete (the stream has been waited for).
+int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n);
+void host_copy_release(ws_ctx *c);
+bool host_copy_in_chunks(const ws_ctx *c, size_t n);      // whether labels_to_host_u64 widens on the host (else: on the device, into c->out64)
 int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *opt, size_t *ph, size_t *pw);
 
 // Runs `launch(pass)` until a pass reports zero changed tile edges.  Passes are launched in GROUPS:

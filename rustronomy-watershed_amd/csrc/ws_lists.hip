@@ -278,9 +278,15 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     HIP_TRY(c, hipMemcpyAsync(bounds.data(), mf + MF_OFF_PX, 2 * (NLEVELS + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   }
   if (out_labels && n) {
-    if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, opt->max_water_level));
-    else HIP_TRY(c, widen_labels(c->stream, seg, d_out64, n));
-    HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (merging && !host_copy_in_chunks(c, n)) {
+      HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, opt->max_water_level));
+      HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    } else {
+      // a large plane crosses the bus as u32 and is widened by host threads (ws_hostcopy.hip); the relabelled u32 plane of
+      // the merging transform borrows the u64 buffer, which that path does not use
+      if (merging) HIP_TRY(c, relabel_u32(c->stream, keys, seg, parent, (uint32_t *)d_out64, n, opt->max_water_level));
+      if ((rc = labels_to_host_u64(c, merging ? (const uint32_t *)d_out64 : seg, out_labels, n))) return rc;
+    }
   }
   rc = stats_end(c);
   if (rc) return rc;

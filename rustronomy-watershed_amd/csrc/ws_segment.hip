@@ -326,7 +326,7 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
   size_t d_stride;
   const uint32_t *d_seeds;
   if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
+  if (cb && (rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;      // the hook's planes are widened on the device
   stats_begin(c);
   if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
   uint32_t *d_labels = (uint32_t *)c->labels.p;
@@ -359,8 +359,7 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
   }
   if (out_labels && n) {
     Span sp(c, KC_OTHER);
-    HIP_TRY(c, widen_labels(c->stream, d_labels, d_out64, n));
-    HIP_TRY(c, hipMemcpyAsync(out_labels, d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = labels_to_host_u64(c, d_labels, out_labels, n))) return rc;
   }
   if (out_labels_u32 && n)      // ws_segment_u32: the device's own 4-byte labels, half the bytes over PCIe
     HIP_TRY(c, hipMemcpyAsync(out_labels_u32, d_labels, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -498,10 +497,9 @@ static int segment_minima_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w
     HIP_TRY(c, widen_pairs(c->stream, d_list, (uint64_t *)c->out64.p, got * 2));
     HIP_TRY(c, hipMemcpyAsync(seeds_rc, c->out64.p, got * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   }
-  if (out64 && n) {
-    if ((rc = ensure(c, c->out64, n * sizeof(uint64_t)))) return rc;
-    HIP_TRY(c, widen_labels(c->stream, (const uint32_t *)c->labels.p, (uint64_t *)c->out64.p, n));
-    HIP_TRY(c, hipMemcpyAsync(out64, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  if (out64 && n) {      // (after the seed pairs' copy has been queued: they share out64 on the small-plane path)
+    if (got) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = labels_to_host_u64(c, (const uint32_t *)c->labels.p, out64, n))) return rc;
   }
   if (out32 && n) HIP_TRY(c, hipMemcpyAsync(out32, c->labels.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

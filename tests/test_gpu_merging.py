@@ -125,12 +125,13 @@ def test_merge_to_list_sparse_core_bench_shape(pkg):
         assert (dense == want[lvl]).all(), lvl
 
 
-def test_merge_final_labels_device_and_host(pkg):
+@pytest.mark.parametrize("shape", [(600, 700), (1100, 1000)])      # the second: the host plane is widened from u32 chunks (ws_hostcopy.hip)
+def test_merge_final_labels_device_and_host(pkg, shape):
     import importlib
     import torch
     dev = importlib.import_module("rustronomy_watershed_amd.device")
     eng = dev.DeviceEngine(0)
-    img = eng.random_field(600, 700, 4)
+    img = eng.random_field(shape[0], shape[1], 4)
     seeds = eng.find_local_minima(img)
     got = eng.merge(img, seeds, max_level=100)
     torch.cuda.synchronize()

@@ -279,6 +279,73 @@ def test_segment_u32_host_labels_equal_the_usize_plane(pkg):
         assert pkg._ffi.lib().ws_segment_u32(c.handle, img.ctypes.data, 300, 420, 420, seeds.ctypes.data, len(seeds), ctypes.byref(opt), None) == pkg._ffi.WS_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("shape", [(1500, 1401), (2048, 3072), (1024, 1024), (2048, 4096), (4099, 2051)])
+def test_usize_host_labels_of_planes_that_cross_the_bus_in_chunks(pkg, shape):
+    # ws_hostcopy.hip: from 2^20 pixels on the u64 plane is not copied but WIDENED by host threads out of 16 MiB chunks of the u32
+    # plane (half a chunk, one and a half, the smallest plane that goes this way, two chunks exactly, two and a few pixels); the
+    # caller's plane may sit on any 8-byte boundary.  Against ws_segment_u32 (one plain copy of the same device labels) and, at the smallest size, the oracle.
+    import ctypes
+    h, w = shape
+    ws = _seg(pkg)
+    c, opt = ws._ctx(), ws._opt
+    img = np.ascontiguousarray(_torch_engine(pkg).random_field(h, w, 5).cpu().numpy())
+    seeds = np.ascontiguousarray(np.asarray(ol.find_local_minima(img), dtype=np.uint64))
+    L = pkg._ffi.lib()
+    out32 = np.zeros((h, w), dtype=np.uint32)
+    assert L.ws_segment_u32(c.handle, img.ctypes.data, h, w, w, seeds.ctypes.data, len(seeds), ctypes.byref(opt), out32.ctypes.data) == 0
+    for shift in (0, 1):
+        buf = np.full(h * w + 3, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+        out = buf[1 + shift:1 + shift + h * w]
+        assert L.ws_segment(c.handle, img.ctypes.data, h, w, w, seeds.ctypes.data, len(seeds), ctypes.byref(opt), out.ctypes.data) == 0
+        assert (out.reshape(h, w) == out32).all()
+        assert buf[shift] == 0xDEADBEEFDEADBEEF and buf[1 + shift + h * w] == 0xDEADBEEFDEADBEEF      # nothing beside the plane
+        n_found = ctypes.c_size_t(0)
+        out[:] = 7
+        assert L.ws_segment_minima(c.handle, img.ctypes.data, h, w, w, ctypes.byref(opt), out.ctypes.data, None, 0, ctypes.byref(n_found)) == 0
+        assert n_found.value == len(seeds) and (out.reshape(h, w) == out32).all()
+    if h * w < 3_000_000:
+        assert (out32 == ol.segment_arrival(img, seeds)).all()
+    # ws_ctx_set_host_threads: none (the plane widened on the device, one copy), one, more than there are chunks' worth of rows
+    out = np.zeros(h * w, dtype=np.uint64)
+    for threads in (0, 1, 7):
+        assert L.ws_ctx_set_host_threads(c.handle, threads) == 0
+        out[:] = 9
+        assert L.ws_segment(c.handle, img.ctypes.data, h, w, w, seeds.ctypes.data, len(seeds), ctypes.byref(opt), out.ctypes.data) == 0
+        assert (out.reshape(h, w) == out32).all(), threads
+    assert L.ws_ctx_set_host_threads(c.handle, -1) == pkg._ffi.WS_ERR_BAD_ARG and L.ws_ctx_set_host_threads(c.handle, 65) == pkg._ffi.WS_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("edge", [False, True])
+def test_long_usize_seed_lists_through_the_host_abi(pkg, edge):
+    # 2.5 M (usize, usize) pairs through ws_segment (copied whole, checked and narrowed by k_narrow_seeds); with the seed_shift option
+    # (edge correction's padded plane, the caller's coordinates moved by (+1, +1)) they move on the way.  Against the device-resident
+    # call with the same list, and the reference's panic for a seed outside the plane (lib.rs:1675-1677) wherever in the list it sits.
+    import ctypes
+    import torch
+    h, w = 2200, 2304
+    eng = _torch_engine(pkg)
+    img_t = eng.random_field(h, w, 11)
+    img = np.ascontiguousarray(img_t.cpu().numpy())
+    rr, cc = np.meshgrid(np.arange(1, h - 1, dtype=np.uint64), np.arange(1, w - 1, dtype=np.uint64), indexing="ij")
+    pick = ((rr + cc) % 2 == 0)
+    seeds = np.ascontiguousarray(np.stack([rr[pick], cc[pick]], axis=1))      # row-major, strictly increasing
+    assert len(seeds) > (1 << 21) + 1000
+    want = eng.segment(img_t, torch.from_numpy(seeds.astype(np.int32)).to(img_t.device), edge=edge, seed_shift=edge)
+    torch.cuda.synchronize()
+    ws = _seg(pkg, edge=edge)
+    c = ws._ctx()
+    opt = pkg._ffi.Options(254, int(edge), 0, 0, int(edge))
+    L = pkg._ffi.lib()
+    e = 2 if edge else 0
+    out = np.zeros((h + e, w + e), dtype=np.uint64)
+    assert L.ws_segment(c.handle, img.ctypes.data, h, w, w, seeds.ctypes.data, len(seeds), ctypes.byref(opt), out.ctypes.data) == 0
+    assert (out == want.cpu().numpy().view(np.uint32)).all()
+    for where in (5, (1 << 21) - 1, (1 << 21) + 7, len(seeds) - 1):
+        bad = seeds.copy()
+        bad[where] = (h - 1, w + 1) if where % 2 else (1 << 40, 3)      # (with the shift the caller's plane is h x w: column w + 1 is outside either way)
+        assert L.ws_segment(c.handle, img.ctypes.data, h, w, w, bad.ctypes.data, len(bad), ctypes.byref(opt), out.ctypes.data) == pkg._ffi.WS_ERR_SEED_OOB
+
+
 @pytest.mark.parametrize("shape,kind", [((96, 128), "noise"), ((257, 512), "noise"), ((300, 420), "noise"), ((130, 96), "smooth"), ((64, 1056), "smooth"),
                                         ((3, 32), "noise"), ((2, 64), "noise"), ((40, 64), "flat")])
 @pytest.mark.parametrize("edge", [False, True])
