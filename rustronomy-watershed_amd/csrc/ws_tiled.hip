@@ -806,12 +806,8 @@ int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t
     if (rc2) return rc2;
     // ---- the rows it owns, widened, into the caller's plane
     const size_t own = (r1 - r0) * pw;
-    if (own) {
-      if ((rc2 = grow(g, me.out64, own * sizeof(uint64_t)))) return rc2;
-      G_HIP(g, widen_labels(s, (const uint32_t *)me.labels.p + (r0 - lo) * pw, (uint64_t *)me.out64.p, own));
-      G_HIP(g, hipMemcpyAsync(out_labels + r0 * pw, me.out64.p, own * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-      G_HIP(g, hipStreamSynchronize(s));
-    }
+    // (as u32 chunks over the rank's own link, widened by host threads of the rank's context: ws_hostcopy.hip)
+    if (own) G_WS(g, me, labels_to_host_u64(me.ctx, (const uint32_t *)me.labels.p + (r0 - lo) * pw, out_labels + r0 * pw, own));
     return WS_OK;
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];

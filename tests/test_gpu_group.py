@@ -113,6 +113,19 @@ def test_tiled_host_equals_oracle_segmenting_and_merging(pkg, n_ranks, shape):
     g.close()
 
 
+def test_tiled_host_blocks_of_more_than_a_chunk_of_labels(pkg):
+    # every rank's rows reach the caller's usize plane as u32 chunks widened by host threads of the rank's context
+    # (ws_hostcopy.hip): blocks of 6.3 M and 2.1 M pixels (above / below one chunk of 2^22 labels), all ranks at it at once
+    img = cases.field(3000, 4200, 23)
+    seeds = ol.find_local_minima(img)
+    want = ol.segment_arrival(img, seeds)
+    for n_ranks in (2, 6):
+        g = Group(pkg, n_ranks)
+        got, _ = g.segment_tiled(img, seeds)
+        assert (got == want).all()
+        g.close()
+
+
 def test_tiled_smooth_field_floods_cross_several_blocks(pkg):
     # few seeds, long floods: chains cross the seams many times and in both directions
     img = cases.smooth_field(600, 512, 3, octaves=5)
