@@ -184,10 +184,16 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
     if (want_list && !fe.on)      // the kernel leaves this level's record count in its counter; offsets are prefix sums, taken on the host
       HIP_TRY(c, emit_lakes(c->stream, parent, (const uint32_t *)c->uf_size.p, n_seeds + 1, d_records, cap, mf + MF_LAKE_COUNT, l));
     if (cb) {
-      if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
-      else HIP_TRY(c, snapshot_level(c->stream, keys, seg, d_out64, n, l));
-      HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (host_copy_in_chunks(c, n)) {      // the level's plane as u32 (in the u64 buffer, which that path leaves alone), widened by host threads
+        if (merging) HIP_TRY(c, relabel_u32(c->stream, keys, seg, parent, (uint32_t *)d_out64, n, l));
+        else HIP_TRY(c, snapshot_level_u32(c->stream, keys, seg, (uint32_t *)d_out64, n, l));
+        if (int rc_copy = labels_to_host_u64(c, (const uint32_t *)d_out64, c->host64.data(), n)) return rc_copy;
+      } else {
+        if (merging) HIP_TRY(c, relabel_u64(c->stream, keys, seg, parent, d_out64, n, l));
+        else HIP_TRY(c, snapshot_level(c->stream, keys, seg, d_out64, n, l));
+        HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+      }
       cb(user, (uint8_t)l, opt->max_water_level, himg, c->host64.data(), ph, pw);        // lib.rs:1510-1518
     }
     return WS_OK;

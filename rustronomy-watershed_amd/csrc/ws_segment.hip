@@ -350,9 +350,14 @@ int segment_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size_t strid
     if (rc) return rc;
     if (cb) {
       for (uint32_t lvl = 0; lvl <= opt->max_water_level; ++lvl) {
-        HIP_TRY(c, snapshot_level(c->stream, (const uint32_t *)c->keys.p, d_labels, d_out64, n, lvl));
-        HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (host_copy_in_chunks(c, n)) {      // the level's plane as u32 (in the u64 buffer, which that path leaves alone), widened by host threads
+          HIP_TRY(c, snapshot_level_u32(c->stream, (const uint32_t *)c->keys.p, d_labels, (uint32_t *)d_out64, n, lvl));
+          if ((rc = labels_to_host_u64(c, (const uint32_t *)d_out64, c->host64.data(), n))) return rc;
+        } else {
+          HIP_TRY(c, snapshot_level(c->stream, (const uint32_t *)c->keys.p, d_labels, d_out64, n, lvl));
+          HIP_TRY(c, hipMemcpyAsync(c->host64.data(), d_out64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
         cb(user, (uint8_t)lvl, opt->max_water_level, himg, c->host64.data(), ph, pw);
       }
     }

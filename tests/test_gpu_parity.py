@@ -181,6 +181,26 @@ def test_transform_history_matches_oracle_per_level(pkg, engine_name):
         assert (got == w).all(), lvl
 
 
+def test_transform_history_of_a_plane_widened_by_host_threads(pkg):
+    # from 2^20 pixels on a hook's plane reaches the host as u32 chunks widened by host threads (ws_hostcopy.hip): segmenting
+    # (a level's snapshot of the stamps) and merging (the level's relabelled plane), every level against the oracle's
+    img = cases.field(1100, 1000, 8)
+    seeds = ol.find_local_minima(img)
+    want = []
+    ol.segment(img, seeds, max_level=9, hook=lambda l, m, i, c: want.append(c.copy()))
+    hist = _seg(pkg, max_level=9).transform_history(img, seeds)
+    assert [l for l, _ in hist] == list(range(10))
+    for (lvl, got), w in zip(hist, want):
+        assert (got == w).all(), lvl
+    wantm = []
+    ol.merge(img, seeds, max_level=9, hook=lambda l, m, i, c: wantm.append(ol.canonicalise(c, seeds)[0]))
+    b = pkg.TransformBuilder.new().set_max_water_lvl(9)
+    histm = b.build_merging().transform_history(img, seeds)
+    assert len(histm) == 10
+    for (lvl, got), w in zip(histm, wantm):
+        assert (got == w).all(), lvl
+
+
 def test_transform_with_hook_receives_hookctx(pkg):
     img = cases.field(50, 60, 6)
     seeds = ol.find_local_minima(img)
