@@ -351,15 +351,12 @@ int ws_find_local_minima(ws_ctx *c, const uint8_t *img, size_t h, size_t w, size
   const size_t bound = ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1);
   const size_t dcap = std::min(cap, bound);
   if ((rc = ensure(c, c->seeds, (dcap ? dcap : 1) * 2 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(c, c->out64, (dcap ? dcap : 1) * 2 * sizeof(uint64_t)))) return rc;
   HIP_TRY(c, hipMemcpy2DAsync(c->img.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
   rc = ws_find_local_minima_device(c, (const uint8_t *)c->img.p, h, w, w, (uint32_t *)c->seeds.p, dcap, n_found);
   if (rc != WS_OK && rc != WS_ERR_CAPACITY) return rc;
   const size_t got = std::min(*n_found, dcap);
-  if (got) {
-    HIP_TRY(c, widen_pairs(c->stream, (const uint32_t *)c->seeds.p, (uint64_t *)c->out64.p, got * 2));
-    HIP_TRY(c, hipMemcpyAsync(out_rc, c->out64.p, got * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (got) {      // (the pairs are 2 x got words: a long list crosses the bus as u32 and is widened by host threads, ws_hostcopy.hip)
+    if (int rc_copy = labels_to_host_u64(c, (const uint32_t *)c->seeds.p, out_rc, got * 2)) return rc_copy;
   }
   return rc;
 }

@@ -497,15 +497,10 @@ static int segment_minima_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w
   const bool short_list = rc == WS_ERR_CAPACITY;
   if (rc != WS_OK && !short_list) return rc;
   const size_t got = std::min(*n_seeds, dcap);
-  if (got) {
-    if ((rc = ensure(c, c->out64, std::max<size_t>(std::max(got * 2, out64 ? n : 0), 1) * sizeof(uint64_t)))) return rc;
-    HIP_TRY(c, widen_pairs(c->stream, d_list, (uint64_t *)c->out64.p, got * 2));
-    HIP_TRY(c, hipMemcpyAsync(seeds_rc, c->out64.p, got * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  }
-  if (out64 && n) {      // (after the seed pairs' copy has been queued: they share out64 on the small-plane path)
-    if (got) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if ((rc = labels_to_host_u64(c, (const uint32_t *)c->labels.p, out64, n))) return rc;
-  }
+  // (pairs and labels alike: u32 over the bus, widened by host threads when there are 2^20 words or more -- ws_hostcopy.hip;
+  // each call returns with its copy complete, so the small-plane path's one staging buffer serves both)
+  if (got && (rc = labels_to_host_u64(c, d_list, seeds_rc, got * 2))) return rc;
+  if (out64 && n && (rc = labels_to_host_u64(c, (const uint32_t *)c->labels.p, out64, n))) return rc;
   if (out32 && n) HIP_TRY(c, hipMemcpyAsync(out32, c->labels.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (seeds_rc && (short_list || *n_seeds > cap)) return fail(c, WS_ERR_CAPACITY, "seed buffer too small (the labels are complete)");

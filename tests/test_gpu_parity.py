@@ -325,6 +325,18 @@ def test_usize_host_labels_of_planes_that_cross_the_bus_in_chunks(pkg, shape):
         assert n_found.value == len(seeds) and (out.reshape(h, w) == out32).all()
     if h * w < 3_000_000:
         assert (out32 == ol.segment_arrival(img, seeds)).all()
+    # the (usize, usize) list takes the same road (2 x n words): ws_find_local_minima, ws_segment_minima with the list wanted, a
+    # list cut short by its capacity (the status survives the copy)
+    got = np.zeros((len(seeds) + 5, 2), dtype=np.uint64)
+    assert L.ws_find_local_minima(c.handle, img.ctypes.data, h, w, w, got.ctypes.data, len(got), ctypes.byref(n_found)) == 0
+    assert n_found.value == len(seeds) and (got[:len(seeds)] == seeds).all() and not got[len(seeds):].any()
+    got[:] = 0
+    out = np.zeros(h * w, dtype=np.uint64)
+    assert L.ws_segment_minima(c.handle, img.ctypes.data, h, w, w, ctypes.byref(opt), out.ctypes.data, got.ctypes.data, len(got), ctypes.byref(n_found)) == 0
+    assert n_found.value == len(seeds) and (got[:len(seeds)] == seeds).all() and (out.reshape(h, w) == out32).all()
+    short = np.zeros((len(seeds) - 3, 2), dtype=np.uint64)
+    assert L.ws_find_local_minima(c.handle, img.ctypes.data, h, w, w, short.ctypes.data, len(short), ctypes.byref(n_found)) == pkg._ffi.WS_ERR_CAPACITY
+    assert n_found.value == len(seeds) and (short == seeds[:len(short)]).all()
     # ws_ctx_set_host_threads: none (the plane widened on the device, one copy), one, more than there are chunks' worth of rows
     out = np.zeros(h * w, dtype=np.uint64)
     for threads in (0, 1, 7):
