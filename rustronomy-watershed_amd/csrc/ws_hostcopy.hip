@@ -19,6 +19,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <memory>
+#include <system_error>
 #include <thread>
 
 namespace wsapi {
@@ -86,16 +87,19 @@ static int host_copy_slots(ws_ctx *c) {
   return WS_OK;
 }
 
+// the plane widened on the device and copied whole (small planes, no host threads)
+static int one_copy(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n) {
+  int rc = ensure(c, c->out64, std::max<size_t>(n, 1) * sizeof(uint64_t));
+  if (rc) return rc;
+  HIP_TRY(c, widen_labels(c->stream, d_labels, (uint64_t *)c->out64.p, n));
+  HIP_TRY(c, hipMemcpyAsync(out, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return WS_OK;
+}
+
 int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n) {
   const int T = host_threads(c);
-  if (!host_copy_in_chunks(c, n)) {
-    int rc = ensure(c, c->out64, std::max<size_t>(n, 1) * sizeof(uint64_t));
-    if (rc) return rc;
-    HIP_TRY(c, widen_labels(c->stream, d_labels, (uint64_t *)c->out64.p, n));
-    HIP_TRY(c, hipMemcpyAsync(out, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return WS_OK;
-  }
+  if (!host_copy_in_chunks(c, n)) return one_copy(c, d_labels, out, n);
   if (int rc = host_copy_slots(c)) return rc;
   const size_t nch = (n + HC_CHUNK - 1) / HC_CHUNK;
   std::atomic<size_t> published{0};      // chunks whose copy has landed in its slot
@@ -115,7 +119,21 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
   };
   std::vector<std::thread> pool;
   pool.reserve(T);
-  for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
+  try {
+    if (tuning_env("WS_HOST_THREADS_FAIL")) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));      // (tuning build: rehearses the catch)
+    for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
+  } catch (const std::system_error &) {      // the process may not start (more) threads: nothing has been published yet
+    abort.store(true);
+    for (auto &th : pool) th.join();
+    // the calling thread widens by itself, chunk after chunk (not one_copy: the source may live in the context's u64 buffer)
+    for (size_t i = 0; i < nch; ++i) {
+      const size_t len = std::min(HC_CHUNK, n - i * HC_CHUNK);
+      HIP_TRY(c, hipMemcpyAsync(stage, d_labels + i * HC_CHUNK, len * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      widen_span(stage, out + i * HC_CHUNK, len);
+    }
+    return WS_OK;
+  }
   hipError_t err = hipSuccess;
   size_t issued = 0, landed = 0, freed = 0;      // freed: chunks every worker has finished (workers take chunks in order)
   while (landed < nch && err == hipSuccess) {

@@ -24,4 +24,4 @@ def run(f, *a):
 m64 = run(L.ws_segment_minima, c.handle, img.ctypes.data, H, W, W, ctypes.byref(opt), out.ctypes.data, None, 0, ctypes.byref(n))
 m32 = run(L.ws_segment_minima_u32, c.handle, img.ctypes.data, H, W, W, ctypes.byref(opt), out32.ctypes.data, None, 0, ctypes.byref(n))
 assert (out == out32).all()
-print(f"threads {os.environ.get('WS_HOST_THREADS', 'default')} chunk 2^{os.environ.get('WS_HOST_CHUNK_LOG2', '21')}: u64 {m64:.2f} ms, u32 {m32:.2f} ms", flush=True)
+print(f"threads {os.environ.get('WS_HOST_THREADS', 'default')} chunk 2^{os.environ.get('WS_HOST_CHUNK_LOG2', '22')}: u64 {m64:.2f} ms, u32 {m32:.2f} ms", flush=True)
