@@ -201,6 +201,48 @@ def end_to_end(pkg, eng, H, W, runs=5):
                     "(ws_ctx_set_host_threads; 0 = one 8-byte copy of a plane widened on the device, as before: 11.5 ms for the one-call form)"}
 
 
+def host_cube(pkg, cube, H, W, runs=3):
+    """c4 from HOST memory: a cube of slices as the reference's own tests walk it (tests/integration.rs:267,356: find_local_minima
+    + transform per slice) -- the loop of ws_segment_minima calls against ONE ws_segment_batch (the slices take turns on internal
+    contexts: upload / transform / label copy of different slices overlap).  u8 slices in, u64 label planes out.  Never `value`."""
+    import ctypes
+    import importlib
+    import numpy as np
+    ffi = importlib.import_module("rustronomy_watershed_amd._ffi")
+    L = ffi.lib()
+    ws = pkg.TransformBuilder.default().build_segmenting()
+    ctx, opt = ws._ctx(), ws._opt
+    N = cube.shape[0]
+    cube = np.ascontiguousarray(cube)
+    a = np.zeros((N, H, W), dtype=np.uint64)
+    b = np.zeros((N, H, W), dtype=np.uint64)
+    n, failed = ctypes.c_size_t(0), ctypes.c_size_t(0)
+
+    def loop():
+        for k in range(N):
+            assert L.ws_segment_minima(ctx.handle, cube[k].ctypes.data, H, W, W, ctypes.byref(opt), a[k].ctypes.data, None, 0, ctypes.byref(n)) == 0
+
+    def batch():
+        assert L.ws_segment_batch(ctx.handle, cube.ctypes.data, N, H, W, W, H * W, None, None, ctypes.byref(opt), b.ctypes.data, None, ctypes.byref(failed)) == 0
+
+    def med(fn):
+        ts = []
+        for i in range(runs + 1):
+            t0 = time.perf_counter()
+            fn()
+            if i >= 1:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+    ms_loop, ms_batch = med(loop), med(batch)
+    same = bool((a == b).all())
+    ctx.close()
+    return {"workload": f"{N} slices of {H}x{W} in host memory, seeds = each slice's find_local_minima, u64 label planes out",
+            "ms_loop_of_ws_segment_minima": round(ms_loop, 2), "ms_ws_segment_batch": round(ms_batch, 2),
+            "Mpixels_per_s": round(N * H * W / ms_batch / 1e3, 1), "same_labels": same,
+            "note": "the link is the bound: 4 B/px of labels down and 1 B/px of image up; one call keeps both directions busy"}
+
+
 def call_pair_device(eng, torch, H, W, runs=9):
     """The README's call pair on device-resident buffers (lib.rs:73-86): find_local_minima + transform as two calls, and as
     ONE (ws_segment_minima_device: the seed tables come out of the minima kernels, no list is written).  One context,
@@ -711,6 +753,8 @@ def run(args):
             out["call_pair"] = call_pair_device(eng, torch, H, W)
             torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(pkg, eng, H, W)
+        if cfg == "c4" and world == 1 and not args.no_extras:
+            out["host_cube"] = host_cube(pkg, cube[:min(len(mine), 16)].cpu().numpy(), H, W)
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, 1, args.cpu_runs, 0 if args.no_cpu_full or cfg != "headline" else H) if (world == 1 and args.cpu_size > 0 and not args.no_extras) else None
         print(json.dumps(out), flush=True)
     if world > 1:

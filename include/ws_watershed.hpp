@@ -259,6 +259,20 @@ class SegmentingWatershed : public Watershed<T> {     // lib.rs:1609-1849
     }
     return out;
   }
+  // Not in the reference: what its integration tests loop over (tests/integration.rs:267,356 -- find_local_minima + transform for
+  // one slice of a cube after the other) as ONE call of the library (ws_segment_batch: the slices' uploads, transforms and label
+  // copies overlap).  `cube`: n_slices contiguous rows x cols slices; slice k of the result is transform_from_minima of slice k.
+  std::vector<Array2<usize>> transform_cube(const std::uint8_t *cube, std::size_t n_slices, std::size_t rows, std::size_t cols) const {
+    const std::size_t e = this->opt_.edge_correction ? 2 : 0, plane = (rows + e) * (cols + e);
+    std::vector<std::uint64_t> flat(n_slices * plane + 1);
+    std::size_t failed = 0;
+    this->ctx_->check(ws_segment_batch(this->ctx_->get(), cube, n_slices, rows, cols, cols, rows * cols, nullptr, nullptr, &this->opt_, flat.data(),
+                                       nullptr, &failed));
+    std::vector<Array2<usize>> out(n_slices, Array2<usize>(rows + e, cols + e));
+    for (std::size_t k = 0; k < n_slices; ++k)
+      for (std::size_t i = 0; i < plane; ++i) out[k].data[i] = (usize)flat[k * plane + i];
+    return out;
+  }
 
  private:
   template <class U> friend class TransformBuilder;

@@ -170,6 +170,9 @@ extern "C" {
         row_stride: usize, seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, lakes: *mut ws_lake,
         cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64) -> c_int;
     pub fn ws_merge_transform_stub(h: usize, w: usize, out_labels: *mut u64) -> c_int;
+    pub fn ws_segment_batch(ctx: *mut ws_ctx, cube: *const u8, n_slices: usize, h: usize, w: usize, row_stride: usize, slice_stride: usize,
+                            seeds_rc: *const u64, seed_offsets: *const usize, opt: *const ws_options, out_labels: *mut u64,
+                            n_seeds: *mut usize, failed_slice: *mut usize) -> c_int;
     pub fn ws_pre_processor(ctx: *mut ws_ctx, data: *const c_void, dtype: c_int, n_elems: usize, max_value: u8,
         out: *mut u8) -> c_int;
 

@@ -392,6 +392,25 @@ impl<T> SegmentingWatershed<T> {
         let seeds = if want_seeds { packed.chunks_exact(2).take(n).map(|p| (p[0] as usize, p[1] as usize)).collect() } else { Vec::new() };
         (out, seeds)
     }
+
+    /// Not in the reference: what its integration tests loop over (tests/integration.rs:267,356 -- `find_local_minima` +
+    /// `transform` for one slice of a cube after the other) as ONE call of the library (`ws_segment_batch`): the slices take
+    /// turns on internal contexts, so one slice's upload, another's transform and a third's label copy overlap.  Slice k of
+    /// the result is exactly `transform(cube[k], &find_local_minima(cube[k]))`.
+    pub fn transform_cube(&self, cube: nd::ArrayView3<u8>) -> nd::Array3<usize> {
+        let (n, h, w) = cube.dim();
+        let std_cube = cube.as_standard_layout();      // contiguous (slice, row, column); a copy only if the view is strided
+        let o = self.opt.ffi();
+        let (ph, pw) = self.opt.plane(h, w);
+        let mut out = nd::Array3::<usize>::zeros((n, ph, pw));
+        let mut failed = 0usize;
+        shim::with_ctx(|ctx| unsafe {
+            let rc = hip_ffi::ws_segment_batch(ctx, std_cube.as_ptr(), n, h, w, w, h * w, std::ptr::null(), std::ptr::null(), &o,
+                                               out.as_mut_ptr() as *mut u64, std::ptr::null_mut(), &mut failed);
+            shim::check(ctx, rc, "ws_segment_batch");
+        });
+        out
+    }
 }
 
 impl<T> Watershed<T> for MergingWatershed<T> {

@@ -395,6 +395,36 @@ class SegmentingWatershed(_Transform):
                      seeds.ctypes.data if want_seeds else None, cap, ctypes.byref(n)))
         return (out, seeds[: n.value].copy()) if want_seeds else out
 
+    def transform_cube(self, cube, seeds=None):
+        """The slices cube[k] of a 3-D u8 array, each as `transform(cube[k], seeds[k])` -- or, with seeds None, as the README's
+        pair `transform(cube[k], &find_local_minima(cube[k]))` -- in ONE call of the library (ws_segment_batch: the slices'
+        uploads, transforms and label copies overlap).  What tests/integration.rs:267,356 loops over.  Returns the label cube
+        (and, with seeds None, the number of minima of every slice).  Not a method of the reference."""
+        c = np.ascontiguousarray(cube, dtype=np.uint8)
+        if c.ndim != 3:
+            raise ValueError("cube must be 3-D: (slices, rows, columns)")
+        n, h, w = c.shape
+        ctx = self._ctx()
+        ph, pw = self._shape(c[0]) if n else (h, w)
+        out = np.empty((n, ph, pw), dtype=np.uint64)
+        counts = np.zeros(max(n, 1), dtype=np.uintp)
+        failed = ctypes.c_size_t(0)
+        if seeds is None:
+            flat, offs = None, None
+        else:
+            if len(seeds) != n:
+                raise ValueError("one seed list per slice")
+            lists = [np.asarray(s, dtype=np.uint64).reshape(-1, 2) for s in seeds]
+            offs = np.zeros(n + 1, dtype=np.uintp)
+            offs[1:] = np.cumsum([len(l) for l in lists])
+            flat = np.ascontiguousarray(np.concatenate(lists, axis=0) if lists else np.zeros((0, 2), dtype=np.uint64))
+            if flat.shape[0] == 0:
+                flat = np.zeros((1, 2), dtype=np.uint64)
+        ctx.check(_ffi.lib().ws_segment_batch(ctx.handle, c.ctypes.data, n, h, w, w, h * w, flat.ctypes.data if flat is not None else None,
+                                              offs.ctypes.data_as(_ffi.szp) if offs is not None else None, ctypes.byref(self._opt),
+                                              out.ctypes.data, counts.ctypes.data_as(_ffi.szp), ctypes.byref(failed)))
+        return out if seeds is not None else (out, counts[:n].astype(np.int64))
+
 
 class MergingWatershed(_Transform):
     """lib.rs:1297-1562"""

@@ -231,6 +231,8 @@ int ws_ctx_create_on_stream(int device, void *hip_stream, ws_ctx **out) { return
 
 void ws_ctx_destroy(ws_ctx *c) {
   if (!c) return;
+  for (ws_ctx *lane : c->lanes) ws_ctx_destroy(lane);
+  c->lanes.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->img, &c->keys, &c->labels, &c->labels2, &c->stamps, &c->flags, &c->seeds, &c->out64, &c->counts, &c->aux, &c->seed_stack, &c->min_counts, &c->min_nibbles, &c->seeds64,

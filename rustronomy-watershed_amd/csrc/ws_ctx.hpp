@@ -63,6 +63,7 @@ struct ws_ctx {
   std::vector<uint64_t> host64;    // hook staging
   uint32_t *hc_stage = nullptr;    // ws_hostcopy.hip: pinned staging slots of the chunked label copy (made on first use)
   hipEvent_t hc_ev[4]{};           // one per slot: its copy has landed
+  std::vector<ws_ctx *> lanes;     // ws_segment_batch: internal contexts the slices of a host cube take turns on (owned; made on first use)
   int host_threads = 4;            // ... and the threads that widen the chunks (ws_ctx_set_host_threads; 0: one 8-byte copy instead)
   std::vector<uint8_t> host_img;
   size_t last_h = 0, last_w = 0;

@@ -2,6 +2,11 @@
 // sequences on one HIP stream, in the fused form (all levels at once) and the literal sweep form.
 #include "ws_ctx.hpp"
 
+#include <atomic>
+#include <mutex>
+#include <system_error>
+#include <thread>
+
 namespace wsapi {
 
 // Seeds reach the kernels in one of two forms.  TABLES: a strictly increasing list (what
@@ -656,6 +661,92 @@ int ws_segment_batch_device(ws_ctx *c, const uint8_t *d_cube, size_t n_slices, s
     const int rc = ws_segment_device(c, d_cube + k * slice_stride, h, w, stride, d_seeds_rc + 2 * seed_offsets[k],
                                      seed_offsets[k + 1] - seed_offsets[k], opt, d_labels + k * plane);
     if (rc != WS_OK) { if (failed_slice) *failed_slice = k; return rc; }
+  }
+  return WS_OK;
+}
+
+// A cube of independent slices in HOST memory (tests/integration.rs:267,356: the reference walks the slices of a CGPS cube one
+// call of transform() after the other).  One slice's call is upload, transform, label copy in a row: the bus idles while the
+// transform runs and carries one direction at a time.  Here the slices take turns on BATCH_LANES internal contexts, each with a
+// host thread and a stream of its own: one slice's image goes up while another's labels come down and a third transforms.
+// Every slice is exactly ws_segment_minima (seeds_rc == NULL) or ws_segment of that slice.
+constexpr int BATCH_LANES = 4;      // (16 x 4096^2, ms per slice: 1 lane 2.3 = the loop, 2: 1.58, 3: 1.50, 4: 1.44, 6: 1.36-1.45; the label copy alone: 1.17)
+
+int ws_segment_batch(ws_ctx *c, const uint8_t *cube, size_t n_slices, size_t h, size_t w, size_t stride, size_t slice_stride,
+                     const uint64_t *seeds_rc, const size_t *seed_offsets, const ws_options *opt, uint64_t *out_labels,
+                     size_t *n_seeds, size_t *failed_slice) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c) return WS_ERR_BAD_ARG;
+  if (failed_slice) *failed_slice = 0;
+  if (n_slices == 0) return WS_OK;
+  if (!opt || !out_labels || (!cube && h * w) || (seeds_rc && !seed_offsets)) return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (n_slices > 1 && slice_stride < h * stride) return fail(c, WS_ERR_BAD_ARG, "slice_stride < h * row_stride");
+  size_t ph, pw;
+  int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
+  if (rc) return rc;
+  if (seeds_rc)
+    for (size_t k = 0; k < n_slices; ++k)
+      if (seed_offsets[k + 1] < seed_offsets[k]) return fail(c, WS_ERR_BAD_ARG, "seed_offsets must not decrease");
+  const size_t plane = ph * pw;
+  static const int max_lanes = [] { const char *e = tuning_env("WS_BATCH_LANES"); return e ? std::max(1, std::min(8, atoi(e))) : BATCH_LANES; }();      // A/B knob, tools/ only
+  const int lanes = (int)std::min<size_t>((size_t)max_lanes, n_slices);
+  while ((int)c->lanes.size() < lanes) {
+    ws_ctx *lane = nullptr;
+    if ((rc = ws_ctx_create(c->device, &lane))) return fail(c, rc, "a lane context of ws_segment_batch could not be created");
+    c->lanes.push_back(lane);
+  }
+  for (int t = 0; t < lanes; ++t) {      // the lanes follow the context's settings
+    ws_ctx *lane = c->lanes[t];
+    lane->host_threads = c->host_threads;
+    lane->seam_min_px = c->seam_min_px;
+    if (lane->persistent_pass != c->persistent_pass) { lane->persistent_pass = c->persistent_pass; ++lane->buffer_generation; }
+  }
+  auto one_slice = [&](ws_ctx *lane, size_t k) -> int {
+    const uint8_t *img = cube + k * slice_stride;
+    uint64_t *out = out_labels + k * plane;
+    if (seeds_rc) {
+      const size_t ns = seed_offsets[k + 1] - seed_offsets[k];
+      if (n_seeds) n_seeds[k] = ns;
+      return segment_host(lane, img, h, w, stride, seeds_rc + 2 * seed_offsets[k], ns, opt, nullptr, nullptr, out);
+    }
+    size_t found = 0;
+    const int r = segment_minima_host(lane, img, h, w, stride, opt, out, nullptr, nullptr, 0, &found);
+    if (n_seeds) n_seeds[k] = found;
+    return r;
+  };
+  std::mutex m;
+  int first_rc = WS_OK;
+  size_t first_slice = 0;
+  std::string first_msg;
+  std::atomic<size_t> stop_at{n_slices};      // the lowest slice that failed so far: slices below it still run, so that the
+  auto run_lane = [&](int t) {                // slice reported is the lowest failing one whatever the lanes' pace
+    ws_ctx *lane = c->lanes[t];
+    for (size_t k = (size_t)t; k < stop_at.load(std::memory_order_relaxed); k += (size_t)lanes) {
+      const int r = one_slice(lane, k);
+      if (r != WS_OK) {
+        std::lock_guard<std::mutex> lk(m);
+        if (first_rc == WS_OK || k < first_slice) { first_rc = r; first_slice = k; first_msg = ws_last_error(lane); }
+        if (k < stop_at.load()) stop_at.store(k);
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  bool threads_ok = true;
+  try {
+    for (int t = 1; t < lanes; ++t) pool.emplace_back(run_lane, t);
+  } catch (const std::system_error &) {
+    threads_ok = false;      // the process may not start threads: the lanes that have none are run below, one after the other
+  }
+  run_lane(0);
+  const int started = (int)pool.size() + 1;
+  for (auto &th : pool) th.join();
+  if (!threads_ok)
+    for (int t = started; t < lanes; ++t) run_lane(t);
+  if (first_rc != WS_OK) {
+    if (failed_slice) *failed_slice = first_slice;
+    c->err = "slice " + std::to_string(first_slice) + ": " + first_msg;
+    return first_rc;
   }
   return WS_OK;
 }

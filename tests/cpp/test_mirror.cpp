@@ -71,6 +71,22 @@ static int gpu_checks() {
   CHECK(mins2 == mins);
   CHECK(std::memcmp(out2.data.data(), want.data(), H * W * 8) == 0);
   CHECK(std::memcmp(watershed.transform_from_minima(rf).data.data(), want.data(), H * W * 8) == 0);
+  // a cube of slices as one call (ws_segment_batch): slice k is the pair of calls on slice k
+  {
+    const size_t N = 5;
+    std::vector<uint8_t> cube(N * H * W);
+    for (size_t k = 0; k < N; ++k) ws_or_random_field(cube.data() + k * H * W, H, W, 20 + k);
+    auto planes = watershed.transform_cube(cube.data(), N, H, W);
+    CHECK(planes.size() == N);
+    for (size_t k = 0; k < N; ++k) {
+      std::vector<uint64_t> rc_k(2 * H * W), want_k(H * W);
+      const size_t n_k = ws_or_find_local_minima(cube.data() + k * H * W, H, W, rc_k.data(), H * W);
+      CHECK(ws_or_segment(cube.data() + k * H * W, H, W, rc_k.data(), n_k, 254, 0, WS_OR_TIE_FIRST, 0, want_k.data(), nullptr, nullptr,
+                          nullptr, nullptr, nullptr) == 0);
+      CHECK(planes[k].rows == H && planes[k].cols == W);
+      CHECK(std::memcmp(planes[k].data.data(), want_k.data(), H * W * 8) == 0);
+    }
+  }
 
   // hook: count coloured pixels per level (HookCtx, lib.rs:844-862) vs the oracle's hook
   struct Acc { std::vector<size_t> v; } acc;

@@ -378,6 +378,64 @@ def test_long_usize_seed_lists_through_the_host_abi(pkg, edge):
         assert L.ws_segment(c.handle, img.ctypes.data, h, w, w, bad.ctypes.data, len(bad), ctypes.byref(opt), out.ctypes.data) == pkg._ffi.WS_ERR_SEED_OOB
 
 
+@pytest.mark.parametrize("edge", [False, True])
+def test_host_cube_of_slices_equals_the_loop_over_them(pkg, edge):
+    # ws_segment_batch: what tests/integration.rs:267,356 loops over (find_local_minima + transform per slice of a cube) as one
+    # call whose slices take turns on three internal contexts.  Every slice against the oracle, with its own minima and with
+    # lists of the caller's (an empty one, unsorted ones); cubes of fewer slices than lanes.
+    import ctypes
+    rng = np.random.default_rng(5)
+    cube = np.stack([cases.field(130, 96, 40 + k) if k % 3 else cases.smooth_field(130, 96, 40 + k) for k in range(7)])
+    ws = _seg(pkg, edge=edge)
+    got, counts = ws.transform_cube(cube)
+    for k in range(7):
+        seeds = ol.find_local_minima(cube[k])
+        assert counts[k] == len(seeds)
+        assert (got[k] == ol.segment(cube[k], seeds, edge=edge)).all(), k
+    lists = []
+    for k in range(7):
+        s = np.asarray(ol.find_local_minima(cube[k]), dtype=np.uint64).reshape(-1, 2)
+        s = s[rng.permutation(len(s))[: len(s) // (k + 1)]] if k != 3 else s[:0]
+        lists.append(s)
+    got = ws.transform_cube(cube, lists)
+    for k in range(7):
+        assert (got[k] == ol.segment(cube[k], lists[k], edge=edge)).all(), k
+    for n in (0, 1, 2):
+        got, counts = ws.transform_cube(cube[:n])
+        assert got.shape[0] == n
+        for k in range(n):
+            assert (got[k] == ol.segment(cube[k], ol.find_local_minima(cube[k]), edge=edge)).all()
+    # the LOWEST failing slice is the one reported, whatever the lanes' pace (lib.rs:1675-1677: the reference panics on a seed
+    # outside the plane, in the first slice that has one)
+    c, L = ws._ctx(), pkg._ffi.lib()
+    e = 2 if edge else 0
+    out = np.zeros((7, 130 + e, 96 + e), dtype=np.uint64)
+    for bad_slices in ((2, 5), (6, 4), (0,), (3, 1, 2)):
+        bad = [l.copy() for l in lists]
+        for k in bad_slices:
+            bad[k] = np.array([[1, 1], [4000 + k, 3]], dtype=np.uint64)
+        flat = np.ascontiguousarray(np.concatenate(bad, axis=0))
+        offs = np.zeros(8, dtype=np.uintp)
+        offs[1:] = np.cumsum([len(l) for l in bad])
+        failed = ctypes.c_size_t(99)
+        rc = L.ws_segment_batch(c.handle, cube.ctypes.data, 7, 130, 96, 96, 130 * 96, flat.ctypes.data, offs.ctypes.data_as(pkg._ffi.szp),
+                                ctypes.byref(ws._opt), out.ctypes.data, None, ctypes.byref(failed))
+        assert rc == pkg._ffi.WS_ERR_SEED_OOB and failed.value == min(bad_slices), (bad_slices, failed.value)
+        assert ("slice %d" % min(bad_slices)).encode() in L.ws_last_error(c.handle)
+    got = ws.transform_cube(cube, lists)      # ... and the context works on
+    assert (got[6] == ol.segment(cube[6], lists[6], edge=edge)).all()
+
+
+def test_host_cube_of_large_slices(pkg):
+    # slices of 2^20 pixels and more: three lanes' label planes are widened by their host threads at once (ws_hostcopy.hip)
+    cube = np.stack([cases.field(1100, 1000, 70 + k) for k in range(5)])
+    ws = _seg(pkg)
+    got, counts = ws.transform_cube(cube)
+    for k in range(5):
+        seeds = ol.find_local_minima(cube[k])
+        assert counts[k] == len(seeds) and (got[k] == ol.segment_arrival(cube[k], seeds)).all(), k
+
+
 @pytest.mark.parametrize("shape,kind", [((96, 128), "noise"), ((257, 512), "noise"), ((300, 420), "noise"), ((130, 96), "smooth"), ((64, 1056), "smooth"),
                                         ((3, 32), "noise"), ((2, 64), "noise"), ((40, 64), "flat")])
 @pytest.mark.parametrize("edge", [False, True])
