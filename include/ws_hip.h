@@ -508,6 +508,15 @@ typedef struct ws_batch_part {
 int ws_segment_batch_group(ws_group *g, size_t h, size_t w, const ws_batch_part *parts, const ws_options *opt,
                            size_t *failed_rank, size_t *failed_slice);
 
+/* The same batch from HOST memory (ws_segment_batch above) over the ranks of a group: rank r takes the slices
+ * [n_slices r / world, n_slices (r + 1) / world) of the cube and pipelines them on its own device -- every device on its own link
+ * to the host, the config-4 shape for a caller whose cube lives in host memory.  Arguments as ws_segment_batch (seed_offsets and
+ * n_seeds index the WHOLE cube); a process drives its local ranks only: in an RCCL group, its one rank's block of slices, read
+ * from and written to that process's pointers.  No exchange step.  *failed_slice: the lowest failing slice of the local ranks. */
+int ws_segment_batch_host(ws_group *g, const uint8_t *cube, size_t n_slices, size_t h, size_t w, size_t row_stride,
+                          size_t slice_stride, const uint64_t *seeds_rc, const size_t *seed_offsets, const ws_options *opt,
+                          uint64_t *out_labels, size_t *n_seeds, size_t *failed_slice);
+
 /* Bench/test synthetic field: v = mix64((seed << 40) + index) % 254. */
 int ws_random_field_device(ws_ctx *ctx, uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                            uint64_t seed);

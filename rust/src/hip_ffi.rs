@@ -173,6 +173,9 @@ extern "C" {
     pub fn ws_segment_batch(ctx: *mut ws_ctx, cube: *const u8, n_slices: usize, h: usize, w: usize, row_stride: usize, slice_stride: usize,
                             seeds_rc: *const u64, seed_offsets: *const usize, opt: *const ws_options, out_labels: *mut u64,
                             n_seeds: *mut usize, failed_slice: *mut usize) -> c_int;
+    pub fn ws_segment_batch_host(g: *mut ws_group, cube: *const u8, n_slices: usize, h: usize, w: usize, row_stride: usize, slice_stride: usize,
+                                 seeds_rc: *const u64, seed_offsets: *const usize, opt: *const ws_options, out_labels: *mut u64,
+                                 n_seeds: *mut usize, failed_slice: *mut usize) -> c_int;
     pub fn ws_pre_processor(ctx: *mut ws_ctx, data: *const c_void, dtype: c_int, n_elems: usize, max_value: u8,
         out: *mut u8) -> c_int;
 

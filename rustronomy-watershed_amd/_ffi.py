@@ -117,6 +117,7 @@ SIGNATURES = {
                                                    szp, vp, vp]),
     "ws_merge_transform_stub": (ctypes.c_int, [sz, sz, vp]),
     "ws_segment_batch": (ctypes.c_int, [vp, vp, sz, sz, sz, sz, sz, vp, szp, ctypes.POINTER(Options), vp, szp, szp]),
+    "ws_segment_batch_host": (ctypes.c_int, [vp, vp, sz, sz, sz, sz, sz, vp, szp, ctypes.POINTER(Options), vp, szp, szp]),
     "ws_find_local_minima_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, szp]),
     "ws_segment_device": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),
     "ws_segment_device_begin": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp]),

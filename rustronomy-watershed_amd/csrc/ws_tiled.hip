@@ -907,4 +907,35 @@ int ws_segment_batch_group(ws_group *g, size_t h, size_t w, const ws_batch_part 
   return rc;
 }
 
+// A cube of independent slices in HOST memory over the ranks of a group: rank r takes the slices [n r / world, n (r + 1) / world)
+// and runs them as ws_segment_batch on its own context -- four lanes per device, every device on its own link to the host.
+// A process drives its local ranks only (an RCCL group: its one rank's block of slices; the cube pointer is that process's).
+int ws_segment_batch_host(ws_group *g, const uint8_t *cube, size_t n_slices, size_t h, size_t w, size_t row_stride, size_t slice_stride,
+                          const uint64_t *seeds_rc, const size_t *seed_offsets, const ws_options *opt, uint64_t *out_labels,
+                          size_t *n_seeds, size_t *failed_slice) {
+  if (failed_slice) *failed_slice = 0;
+  int rc = check_group_call(g, opt);
+  if (rc) return rc;
+  if (n_slices == 0) return WS_OK;
+  if (!out_labels || (!cube && h * w) || (seeds_rc && !seed_offsets)) return gfail(g, WS_ERR_BAD_ARG, "null pointer");
+  const size_t e = opt->edge_correction ? 2 : 0, plane = (h + e) * (w + e);
+  const size_t world = (size_t)g->world;
+  std::vector<size_t> bad(g->ranks.size(), 0);
+  std::vector<int> rcs(g->ranks.size(), WS_OK);
+  rc = for_local_ranks(g, [&](Rank &me) -> int {
+    const size_t i = (size_t)(me.rank - g->first_local);
+    const size_t k0 = n_slices * (size_t)me.rank / world, k1 = n_slices * ((size_t)me.rank + 1) / world;
+    if (k1 == k0) return WS_OK;
+    // (the rank's seed offsets as they are: ws_segment_batch only looks at differences and at seeds_rc + 2 * offset)
+    rcs[i] = ws_segment_batch(me.ctx, cube + k0 * slice_stride, k1 - k0, h, w, row_stride, slice_stride, seeds_rc, seeds_rc ? seed_offsets + k0 : nullptr,
+                              opt, out_labels + k0 * plane, n_seeds ? n_seeds + k0 : nullptr, &bad[i]);
+    bad[i] += k0;
+    if (rcs[i] != WS_OK) return gfail(g, rcs[i], std::string("rank ") + std::to_string(me.rank) + ": ws_segment_batch: " + ws_last_error(me.ctx));
+    return WS_OK;
+  });
+  for (size_t i = 0; i < rcs.size(); ++i)      // ranks hold increasing blocks of slices: the first failing rank has the lowest failing slice
+    if (rcs[i] != WS_OK) { if (failed_slice) *failed_slice = bad[i]; break; }
+  return rc;
+}
+
 }  // extern "C"

@@ -172,3 +172,26 @@ class Group:
         fr, fs = ctypes.c_size_t(), ctypes.c_size_t()
         opt = _ffi.Options(max_level)
         self._check(_ffi.lib().ws_segment_batch_group(self._h, h, w, arr, ctypes.byref(opt), ctypes.byref(fr), ctypes.byref(fs)), "ws_segment_batch_group")
+
+    def segment_batch_host(self, cube, seeds=None, max_level=254, edge=False):
+        """A cube (S, h, w) of uint8 slices in HOST memory (numpy) over the ranks of the group (ws_segment_batch_host): rank r takes
+        a block of the slices and pipelines them on its device.  seeds: None (every slice's find_local_minima) or one (n, 2) list
+        per slice.  Returns the uint64 label cube (and the minima counts with seeds None)."""
+        import numpy as np
+        c = np.ascontiguousarray(cube, dtype=np.uint8)
+        n, h, w = c.shape
+        e = 2 if edge else 0
+        out = np.zeros((n, h + e, w + e), dtype=np.uint64)
+        counts = np.zeros(max(n, 1), dtype=np.uintp)
+        flat = offs = None
+        if seeds is not None:
+            lists = [np.asarray(s, dtype=np.uint64).reshape(-1, 2) for s in seeds]
+            offs = np.zeros(n + 1, dtype=np.uintp)
+            offs[1:] = np.cumsum([len(l) for l in lists])
+            flat = np.ascontiguousarray(np.concatenate(lists + [np.zeros((1, 2), dtype=np.uint64)], axis=0))
+        fs = ctypes.c_size_t()
+        opt = _ffi.Options(max_level, int(edge))
+        self._check(_ffi.lib().ws_segment_batch_host(self._h, c.ctypes.data, n, h, w, w, h * w, flat.ctypes.data if flat is not None else None,
+                                                     offs.ctypes.data_as(_ffi.szp) if offs is not None else None, ctypes.byref(opt), out.ctypes.data,
+                                                     counts.ctypes.data_as(_ffi.szp), ctypes.byref(fs)), "ws_segment_batch_host")
+        return out if seeds is not None else (out, counts[:n].astype(np.int64))

@@ -126,6 +126,57 @@ def test_tiled_host_blocks_of_more_than_a_chunk_of_labels(pkg):
         g.close()
 
 
+@pytest.mark.parametrize("n_ranks,rccl", [(1, False), (2, False), (3, False), (1, True)])
+def test_host_cube_over_the_ranks_of_a_group(pkg, n_ranks, rccl):
+    # ws_segment_batch_host: rank r pipelines its block of the slices (ws_segment_batch on its own context); with more ranks than
+    # slices some ranks idle.  Every slice against the oracle -- with its own minima, with the caller's lists, with edge correction
+    # -- and the lowest failing slice named (lib.rs:1675-1677).
+    rng = np.random.default_rng(3)
+    cube = np.stack([cases.field(100, 72, 60 + k) if k % 2 else cases.smooth_field(100, 72, 60 + k) for k in range(8)])
+    g = Group(pkg, n_ranks, rccl=rccl)
+    L = g.L
+
+    def run(n, lists, edge, expect=0):
+        e = 2 if edge else 0
+        out = np.zeros((max(n, 1), 100 + e, 72 + e), dtype=np.uint64)
+        counts = np.zeros(max(n, 1), dtype=np.uintp)
+        failed = ctypes.c_size_t(77)
+        opt = pkg._ffi.Options(254, int(edge))
+        flat = offs = None
+        if lists is not None:
+            offs = np.zeros(n + 1, dtype=np.uintp)
+            offs[1:] = np.cumsum([len(l) for l in lists[:n]])
+            flat = np.ascontiguousarray(np.concatenate(list(lists[:n]) + [np.zeros((1, 2), dtype=np.uint64)], axis=0))
+        rc = L.ws_segment_batch_host(g.h, cube.ctypes.data, n, 100, 72, 72, 100 * 72, flat.ctypes.data if flat is not None else None,
+                                     offs.ctypes.data_as(pkg._ffi.szp) if offs is not None else None, ctypes.byref(opt), out.ctypes.data,
+                                     counts.ctypes.data_as(pkg._ffi.szp), ctypes.byref(failed))
+        assert rc == expect, (rc, g.err())
+        return out, counts, failed.value
+
+    for edge in (False, True):
+        for n in (8, 5, 1, 0):
+            out, counts, _ = run(n, None, edge)
+            for k in range(n):
+                seeds = ol.find_local_minima(cube[k])
+                assert counts[k] == len(seeds) and (out[k] == ol.segment(cube[k], seeds, edge=edge)).all(), (n, k)
+    lists = []
+    for k in range(8):
+        s = np.asarray(ol.find_local_minima(cube[k]), dtype=np.uint64).reshape(-1, 2)
+        lists.append(s[rng.permutation(len(s))[: len(s) // (k + 1)]] if k != 4 else s[:0])
+    out, counts, _ = run(8, lists, False)
+    for k in range(8):
+        assert counts[k] == len(lists[k]) and (out[k] == ol.segment(cube[k], lists[k])).all(), k
+    for bad_slices in ((6, 3), (7,), (0, 5)):
+        bad = [l.copy() for l in lists]
+        for k in bad_slices:
+            bad[k] = np.array([[2, 2], [3000 + k, 1]], dtype=np.uint64)
+        _, _, failed = run(8, bad, False, expect=pkg._ffi.WS_ERR_SEED_OOB)
+        assert failed == min(bad_slices), (bad_slices, failed)
+    out, _, _ = run(8, lists, False)      # the group works on
+    assert (out[7] == ol.segment(cube[7], lists[7])).all()
+    g.close()
+
+
 def test_tiled_smooth_field_floods_cross_several_blocks(pkg):
     # few seeds, long floods: chains cross the seams many times and in both directions
     img = cases.smooth_field(600, 512, 3, octaves=5)
