@@ -177,8 +177,8 @@ int ws_ctx_set_seam_repair_min_pixels(ws_ctx *ctx, size_t min_px);
  * Transforms that converge in a few passes (random fields) never reach those passes.  WS_ERR_BAD_ARG for any other mode. */
 int ws_ctx_set_persistent_pass(ws_ctx *ctx, int mode);
 /* Host threads the host-buffer entry points may start for the length of a call (default 4, at most 64, never more than the
- * machine has): from 2^20 pixels on a u64 label plane (ws_segment, ws_segment_minima, ws_merge ...) crosses the bus as the device's
- * u32 plane in 16 MiB chunks and these threads widen each chunk into the caller's memory while the next ones are in flight --
+ * machine has): from 2^21 pixels on a u64 label plane (ws_segment, ws_segment_minima, ws_merge ...) crosses the bus as the device's
+ * u32 plane in chunks (a quarter of the plane, 16 MiB at most) and these threads widen each chunk into the caller's memory while the next ones are in flight --
  * half the bytes over PCIe (8192^2: ws_segment_minima 11.5 -> 7.2 ms).  0: no threads, the plane is widened on the device and
  * copied whole, as before. */
 int ws_ctx_set_host_threads(ws_ctx *ctx, int n_threads);
@@ -200,7 +200,7 @@ int ws_find_local_minima(ws_ctx *ctx, const uint8_t *img, size_t h, size_t w, si
                          uint64_t *out_rc, size_t cap, size_t *n_found);
 
 /* Watershed::transform for SegmentingWatershed (lib.rs:1810-1822, intended semantics).
- * out_labels is the reference's Array2<usize> plane.  From 2^20 pixels on the labels cross the bus as the device's u32 plane, in
+ * out_labels is the reference's Array2<usize> plane.  From 2^21 pixels on the labels cross the bus as the device's u32 plane, in
  * chunks, and host threads of the library (ws_ctx_set_host_threads: four; 0 = none, one 8-byte copy) widen them into
  * out_labels while the next chunks are in flight: 8192^2 9.2 ms instead of 13.7.  The threads live for
  * the call only. */

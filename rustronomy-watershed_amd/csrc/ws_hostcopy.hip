@@ -27,13 +27,19 @@ namespace wsapi {
 namespace {
 
 constexpr size_t HC_CHUNK_MAX = (size_t)1 << 22;      // labels per chunk: 16 MiB over the bus, 32 MiB written
+constexpr size_t HC_CHUNK_MIN = (size_t)1 << 19;
 constexpr int HC_SLOTS = 4;
-#ifdef WS_TUNING
-static const size_t HC_CHUNK = [] { const char *e = tuning_env("WS_HOST_CHUNK_LOG2"); return e ? std::min(HC_CHUNK_MAX, (size_t)1 << std::atoi(e)) : HC_CHUNK_MAX; }();
-#else
-constexpr size_t HC_CHUNK = HC_CHUNK_MAX;
-#endif
-constexpr size_t HC_MIN = (size_t)1 << 20;        // planes below this take the one-copy path: the threads cost more than they hide
+// planes below this take the one-copy path: starting the threads costs more than they hide (ws_segment_minima, u64 labels,
+// one copy / chunks: 1024^2 0.32 / 0.40 ms, 1448^2 0.52 / 0.54, 2048^2 0.84 / 0.74-0.79, 4096^2 2.9 / 2.1, 8192^2 11.5 / 7.1)
+constexpr size_t HC_MIN = (size_t)1 << 21;
+
+// a quarter of the plane, so that planes of a few chunks' worth still overlap their copies with the widening (2048^2: one chunk
+// of 2^22 0.92 ms, four of 2^20 0.74), between 2^19 and 2^22 labels
+size_t chunk_of(size_t n) {
+  size_t ch = std::min(HC_CHUNK_MAX, std::max(HC_CHUNK_MIN, ((n + 3) / 4 + 4095) & ~(size_t)4095));
+  if (const char *e = tuning_env("WS_HOST_CHUNK_LOG2")) ch = std::min(HC_CHUNK_MAX, (size_t)1 << atoi(e));      // A/B knob, tools/ only
+  return ch;
+}
 
 // threads of ws_ctx_set_host_threads (default 4: 2 .. 8 threads and chunks of 2^21 .. 2^23 labels all take 7.1-7.4 ms at 8192^2),
 // never more than the machine has
@@ -101,6 +107,7 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
   const int T = host_threads(c);
   if (!host_copy_in_chunks(c, n)) return one_copy(c, d_labels, out, n);
   if (int rc = host_copy_slots(c)) return rc;
+  const size_t HC_CHUNK = chunk_of(n);
   const size_t nch = (n + HC_CHUNK - 1) / HC_CHUNK;
   std::atomic<size_t> published{0};      // chunks whose copy has landed in its slot
   std::atomic<bool> abort{false};

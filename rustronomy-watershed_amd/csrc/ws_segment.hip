@@ -502,7 +502,7 @@ static int segment_minima_host(ws_ctx *c, const uint8_t *img, size_t h, size_t w
   const bool short_list = rc == WS_ERR_CAPACITY;
   if (rc != WS_OK && !short_list) return rc;
   const size_t got = std::min(*n_seeds, dcap);
-  // (pairs and labels alike: u32 over the bus, widened by host threads when there are 2^20 words or more -- ws_hostcopy.hip;
+  // (pairs and labels alike: u32 over the bus, widened by host threads when there are 2^21 words or more -- ws_hostcopy.hip;
   // each call returns with its copy complete, so the small-plane path's one staging buffer serves both)
   if (got && (rc = labels_to_host_u64(c, d_list, seeds_rc, got * 2))) return rc;
   if (out64 && n && (rc = labels_to_host_u64(c, (const uint32_t *)c->labels.p, out64, n))) return rc;

@@ -115,7 +115,7 @@ def test_tiled_host_equals_oracle_segmenting_and_merging(pkg, n_ranks, shape):
 
 def test_tiled_host_blocks_of_more_than_a_chunk_of_labels(pkg):
     # every rank's rows reach the caller's usize plane as u32 chunks widened by host threads of the rank's context
-    # (ws_hostcopy.hip): blocks of 6.3 M and 2.1 M pixels (above / below one chunk of 2^22 labels), all ranks at it at once
+    # (ws_hostcopy.hip): blocks of 6.3 M and 2.1 M pixels (four chunks of 1.6 M / of 2^19 labels), all ranks at it at once
     img = cases.field(3000, 4200, 23)
     seeds = ol.find_local_minima(img)
     want = ol.segment_arrival(img, seeds)

@@ -125,7 +125,7 @@ def test_merge_to_list_sparse_core_bench_shape(pkg):
         assert (dense == want[lvl]).all(), lvl
 
 
-@pytest.mark.parametrize("shape", [(600, 700), (1100, 1000)])      # the second: the host plane is widened from u32 chunks (ws_hostcopy.hip)
+@pytest.mark.parametrize("shape", [(600, 700), (1500, 1400)])      # the second: the host plane is widened from u32 chunks (ws_hostcopy.hip)
 def test_merge_final_labels_device_and_host(pkg, shape):
     import importlib
     import torch

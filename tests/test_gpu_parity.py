@@ -182,9 +182,9 @@ def test_transform_history_matches_oracle_per_level(pkg, engine_name):
 
 
 def test_transform_history_of_a_plane_widened_by_host_threads(pkg):
-    # from 2^20 pixels on a hook's plane reaches the host as u32 chunks widened by host threads (ws_hostcopy.hip): segmenting
+    # from 2^21 pixels on a hook's plane reaches the host as u32 chunks widened by host threads (ws_hostcopy.hip): segmenting
     # (a level's snapshot of the stamps) and merging (the level's relabelled plane), every level against the oracle's
-    img = cases.field(1100, 1000, 8)
+    img = cases.field(1500, 1400, 8)
     seeds = ol.find_local_minima(img)
     want = []
     ol.segment(img, seeds, max_level=9, hook=lambda l, m, i, c: want.append(c.copy()))
@@ -299,11 +299,11 @@ def test_segment_u32_host_labels_equal_the_usize_plane(pkg):
         assert pkg._ffi.lib().ws_segment_u32(c.handle, img.ctypes.data, 300, 420, 420, seeds.ctypes.data, len(seeds), ctypes.byref(opt), None) == pkg._ffi.WS_ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("shape", [(1500, 1401), (2048, 3072), (1024, 1024), (2048, 4096), (4099, 2051)])
+@pytest.mark.parametrize("shape", [(1500, 1401), (2048, 3072), (1024, 2048), (4096, 4096), (4099, 5003)])
 def test_usize_host_labels_of_planes_that_cross_the_bus_in_chunks(pkg, shape):
-    # ws_hostcopy.hip: from 2^20 pixels on the u64 plane is not copied but WIDENED by host threads out of 16 MiB chunks of the u32
-    # plane (half a chunk, one and a half, the smallest plane that goes this way, two chunks exactly, two and a few pixels); the
-    # caller's plane may sit on any 8-byte boundary.  Against ws_segment_u32 (one plain copy of the same device labels) and, at the smallest size, the oracle.
+    # ws_hostcopy.hip: from 2^21 pixels on the u64 plane is not copied but WIDENED by host threads out of chunks of the u32 plane
+    # (a quarter of the plane each, 2^19 .. 2^22 labels: four chunks and a few pixels, four exactly, the smallest plane that goes
+    # this way, four of the largest chunks, five of them and a rest); the caller's plane may sit on any 8-byte boundary.  Against ws_segment_u32 (one plain copy of the same device labels) and, at the smallest size, the oracle.
     import ctypes
     h, w = shape
     ws = _seg(pkg)
@@ -325,7 +325,7 @@ def test_usize_host_labels_of_planes_that_cross_the_bus_in_chunks(pkg, shape):
         assert n_found.value == len(seeds) and (out.reshape(h, w) == out32).all()
     if h * w < 3_000_000:
         assert (out32 == ol.segment_arrival(img, seeds)).all()
-    # the (usize, usize) list takes the same road (2 x n words): ws_find_local_minima, ws_segment_minima with the list wanted, a
+    # the (usize, usize) list (from 2^21 words on: the two largest planes here) takes the same road (2 x n words): ws_find_local_minima, ws_segment_minima with the list wanted, a
     # list cut short by its capacity (the status survives the copy)
     got = np.zeros((len(seeds) + 5, 2), dtype=np.uint64)
     assert L.ws_find_local_minima(c.handle, img.ctypes.data, h, w, w, got.ctypes.data, len(got), ctypes.byref(n_found)) == 0
@@ -427,8 +427,8 @@ def test_host_cube_of_slices_equals_the_loop_over_them(pkg, edge):
 
 
 def test_host_cube_of_large_slices(pkg):
-    # slices of 2^20 pixels and more: three lanes' label planes are widened by their host threads at once (ws_hostcopy.hip)
-    cube = np.stack([cases.field(1100, 1000, 70 + k) for k in range(5)])
+    # slices of 2^21 pixels and more: the lanes' label planes are widened by their host threads at once (ws_hostcopy.hip)
+    cube = np.stack([cases.field(1500, 1400, 70 + k) for k in range(5)])
     ws = _seg(pkg)
     got, counts = ws.transform_cube(cube)
     for k in range(5):
