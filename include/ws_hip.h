@@ -267,7 +267,8 @@ int ws_merge_transform_stub(size_t h, size_t w, uint64_t *out_labels);
  * k * (padded plane).  Equivalent to n_slices calls of ws_segment (ws_segment_minima) and bit-identical to them; the slices take
  * turns on four internal contexts with a stream each and a host thread each for the length of the call, so that one slice's
  * upload, another's transform and a third's label copy overlap on the two directions of the link: 16 x 4096^2 in 23 ms against
- * 34 ms for the loop (1.44 ms a slice; its labels alone take the link 1.17).  On an error the lowest failing slice is reported in *failed_slice (nullable), its message through ws_last_error. */
+ * 34 ms for the loop (1.44 ms a slice; its labels alone take the link 1.17).  The context's statistics (ws_ctx_get_stats) and last
+ * arrival stamps are not those of any slice afterwards.  On an error the lowest failing slice is reported in *failed_slice (nullable), its message through ws_last_error. */
 int ws_segment_batch(ws_ctx *ctx, const uint8_t *cube, size_t n_slices, size_t h, size_t w, size_t row_stride,
                      size_t slice_stride, const uint64_t *seeds_rc, const size_t *seed_offsets, const ws_options *opt,
                      uint64_t *out_labels, size_t *n_seeds, size_t *failed_slice);
