@@ -347,6 +347,28 @@ def test_usize_host_labels_of_planes_that_cross_the_bus_in_chunks(pkg, shape):
     assert L.ws_ctx_set_host_threads(c.handle, -1) == pkg._ffi.WS_ERR_BAD_ARG and L.ws_ctx_set_host_threads(c.handle, 65) == pkg._ffi.WS_ERR_BAD_ARG
 
 
+def test_usize_planes_of_random_shapes_equal_the_u32_planes(pkg):
+    # the chunk arithmetic of ws_hostcopy.hip on odd sizes: planes of 2.1 .. 9 M pixels of random shape (chunks that are not a
+    # multiple of the row, a last chunk of any length, threads 1 .. 6), the usize plane against the device's own u32 plane
+    import ctypes
+    rng = np.random.default_rng(99)
+    eng = _torch_engine(pkg)
+    ws = _seg(pkg)
+    c, opt, L = ws._ctx(), ws._opt, pkg._ffi.lib()
+    n_found = ctypes.c_size_t(0)
+    for case in range(10):
+        h = int(rng.integers(700, 3000))
+        w = int(rng.integers((1 << 21) // h + 1, 9_000_000 // h))
+        img = np.ascontiguousarray(eng.random_field(h, w, 300 + case).cpu().numpy())
+        out32 = np.zeros((h, w), dtype=np.uint32)
+        out64 = np.full(h * w + 1, 5, dtype=np.uint64)
+        assert L.ws_ctx_set_host_threads(c.handle, 1 + case % 6) == 0
+        assert L.ws_segment_minima_u32(c.handle, img.ctypes.data, h, w, w, ctypes.byref(opt), out32.ctypes.data, None, 0, ctypes.byref(n_found)) == 0
+        assert L.ws_segment_minima(c.handle, img.ctypes.data, h, w, w, ctypes.byref(opt), out64[case % 2:].ctypes.data, None, 0, ctypes.byref(n_found)) == 0
+        assert (out64[case % 2:case % 2 + h * w].reshape(h, w) == out32).all(), (h, w)
+        assert out64[h * w if case % 2 == 0 else 0] == 5
+
+
 @pytest.mark.parametrize("edge", [False, True])
 def test_long_usize_seed_lists_through_the_host_abi(pkg, edge):
     # 2.5 M (usize, usize) pairs through ws_segment (copied whole, checked and narrowed by k_narrow_seeds); with the seed_shift option
