@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 import torch
+torch.cuda.set_stream(torch.cuda.Stream(0))      # not the legacy null stream: the engine's graph replay needs a capturable stream (as bench.py)
 eng = importlib.import_module('rustronomy_watershed_amd.device').DeviceEngine(0)
 L = pkg._ffi.lib()
 ws = pkg.api.TransformBuilder().build_segmenting()
