@@ -13,6 +13,11 @@ from .api import Context, ENGINE_AUTO
 
 
 class DeviceEngine:
+    """One engine context on torch's CURRENT stream of the device.  Create it under a stream of your own
+    (`torch.cuda.set_stream(torch.cuda.Stream(dev))`, as bench.py does) rather than on the legacy default stream: a repeated
+    transform is replayed as one hipGraph, and HIP cannot capture on the legacy stream -- there every transform is its eleven
+    stream operations (2048^2: 0.155 instead of 0.123 ms; results are the same)."""
+
     def __init__(self, device_index=0, engine=ENGINE_AUTO):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceEngine needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
