@@ -103,6 +103,23 @@ def test_headline_field_8192_equals_oracle(pkg):
     got = (out.to(torch.int64) & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
     bad = int((got != want).sum())
     assert bad == 0, f"{bad} labels of the headline field differ from the oracle"
+    # ... and by the route bench.py times: a context on a stream of its own, the same buffers again and again -- the third
+    # transform on is ONE replayed hipGraph -- and as begin / end halves; label by label what the oracle confirmed above
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    with torch.cuda.stream(torch.cuda.Stream()):      # (the legacy null stream cannot be captured)
+        eng2 = dev.DeviceEngine(0)
+        out2 = torch.zeros_like(out)
+        for rep in range(4):
+            out2.zero_()
+            eng2.segment(d_img, d_seeds, out=out2)
+            if rep >= 2:
+                assert eng2.stats()["graph_launches"] == 1, rep
+            assert bool((out2 == out).all()), rep
+        out2.zero_()
+        eng2.segment_begin(d_img, d_seeds, out2)
+        eng2.segment_end()
+        assert eng2.stats()["graph_launches"] == 1 and bool((out2 == out).all())
+        torch.cuda.current_stream().synchronize()
 
 
 @pytest.mark.parametrize("max_level", [100, 200])
