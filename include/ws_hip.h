@@ -327,6 +327,15 @@ int ws_merge_device_end(ws_ctx *ctx);
 int ws_transform_to_list_device(ws_ctx *ctx, int merging, const uint8_t *d_img, size_t h, size_t w, size_t row_stride,
                                 const uint32_t *d_seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *d_lakes,
                                 size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured);
+
+/* The same lists from a segmenting transform that has already run -- here or on other devices: d_keys = its arrival stamps
+ * (ws_last_arrival_device / ws_copy_last_arrival_device), d_seg_labels = its labels, both h x w u32 planes as they stand (a
+ * padded plane is passed padded; opt->edge_correction is ignored), n_seeds = the number of colours.  Everything the per-level
+ * paths read is in those two planes: no image, no seed list, no second flood.  Records, offsets, uncoloured and
+ * WS_ERR_CAPACITY as ws_transform_to_list_device. */
+int ws_lists_from_arrival_device(ws_ctx *ctx, int merging, const uint32_t *d_keys, const uint32_t *d_seg_labels, size_t h, size_t w,
+                                 size_t n_seeds, const ws_options *opt, ws_lake *d_lakes, size_t cap, size_t *n_lakes,
+                                 uint64_t *offsets, uint64_t *uncoloured);
 /* Arrival stamps of the last ws_segment_device / ws_merge_device call on this context:
  * (level << 24 | ring), 0 for seeds, 0xFF000000 for never coloured.  Device pointer owned
  * by the context, valid until the next call; shape as the label plane. */
@@ -470,6 +479,17 @@ typedef struct ws_tile_block {
 int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seeds_total, const ws_tile_block *blocks,
                             const ws_options *opt /* edge_correction must be 0: pad the field first */, int merging,
                             uint32_t *exchange_rounds);
+
+/* transform_to_list (lib.rs:1551-1561 merging, 1837-1847 segmenting) of a field in row blocks (blocks as for
+ * ws_segment_tiled_device, whose segmenting transform runs first and leaves every block's labels in d_labels): the ranks then
+ * send the arrival stamps and labels of their owned rows to rank 0 (8 B per pixel, one message per rank and plane), and rank
+ * 0's context writes the lake records of all levels from the whole plane (ws_lists_from_arrival_device).  d_lakes (cap
+ * records, on rank 0's device), n_lakes, offsets (max_water_level + 2) and uncoloured (max_water_level + 1) are filled in the
+ * process that holds rank 0; elsewhere *n_lakes = 0 and the arrays are left alone.  A lake spans blocks and its area is a sum
+ * over them: the lists are global, so they are made where the whole plane is -- 28 B per pixel of one device's 288 GB. */
+int ws_transform_to_list_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seeds_total, const ws_tile_block *blocks,
+                                      const ws_options *opt, int merging, ws_lake *d_lakes, size_t cap, size_t *n_lakes,
+                                      uint64_t *offsets, uint64_t *uncoloured, uint32_t *exchange_rounds);
 
 /* The field cut in BOTH directions (BASELINE config 5's "2-D tiles"): py x px tiles, rank = ty * px + tx, py * px = the
  * group's ranks.  ws_tile_grid: rows[4] = {r0, r1, lo, hi} and cols[4] = {c0, c1, clo, chi} of a rank's tile -- owned

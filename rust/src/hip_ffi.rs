@@ -169,6 +169,8 @@ extern "C" {
     pub fn ws_transform_to_list(ctx: *mut ws_ctx, merging: c_int, img: *const u8, h: usize, w: usize,
         row_stride: usize, seeds_rc: *const u64, n_seeds: usize, opt: *const ws_options, lakes: *mut ws_lake,
         cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64) -> c_int;
+    pub fn ws_lists_from_arrival_device(ctx: *mut ws_ctx, merging: c_int, d_keys: *const u32, d_seg_labels: *const u32, h: usize, w: usize, n_seeds: usize,
+                                        opt: *const ws_options, d_lakes: *mut ws_lake, cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64) -> c_int;
     pub fn ws_merge_transform_stub(h: usize, w: usize, out_labels: *mut u64) -> c_int;
     pub fn ws_segment_batch(ctx: *mut ws_ctx, cube: *const u8, n_slices: usize, h: usize, w: usize, row_stride: usize, slice_stride: usize,
                             seeds_rc: *const u64, seed_offsets: *const usize, opt: *const ws_options, out_labels: *mut u64,
@@ -247,6 +249,9 @@ extern "C" {
         n_seeds: usize, opt: *const ws_options, merging: c_int, out_labels: *mut u64, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block,
         opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_transform_to_list_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block, opt: *const ws_options,
+                                             merging: c_int, d_lakes: *mut ws_lake, cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64,
+                                             exchange_rounds: *mut u32) -> c_int;
     pub fn ws_tile_grid(h: usize, w: usize, rank: c_int, py: c_int, px: c_int, rows: *mut usize, cols: *mut usize) -> c_int;
     pub fn ws_segment_tiled2d_device(g: *mut ws_group, field_h: usize, field_w: usize, py: c_int, px: c_int, n_seeds_total: usize,
         blocks: *const ws_tile_block2d, opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;

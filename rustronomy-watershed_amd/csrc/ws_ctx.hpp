@@ -108,10 +108,11 @@ struct ws_ctx {
     uint32_t levels = 0;
     size_t n_colours = 0, n = 0, cap = 0;
     const void *records = nullptr;      // the buffer the lake records go to (the context's, or a caller's device buffer)
+    const void *keys = nullptr, *seg = nullptr;      // the planes the buckets are built from (the context's, or a caller's: the arrival form)
     uint64_t generation = 0;
     bool operator==(const ListKey &o) const {
       return generation == o.generation && generation != 0 && merging == o.merging && want_list == o.want_list && levels == o.levels &&
-             n_colours == o.n_colours && n == o.n && cap == o.cap && records == o.records;
+             n_colours == o.n_colours && n == o.n && cap == o.cap && records == o.records && keys == o.keys && seg == o.seg;
     }
   };
   ListKey list_graph_key, list_seen_key;

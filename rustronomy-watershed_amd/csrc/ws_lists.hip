@@ -118,35 +118,43 @@ struct DeviceLists {
   const uint8_t *d_img;
   const uint32_t *d_seeds_rc;
   ws_lake *d_lakes;
+  // the arrival form (ws_lists_from_arrival_device): the segmenting transform has been run elsewhere -- its stamps and labels
+  // are all the per-level paths read; no image, no seed list, h x w is the plane as it stands
+  const uint32_t *d_keys = nullptr, *d_seg = nullptr;
 };
 int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
                size_t n_seeds, const ws_options *opt, ws_level_cb cb, void *user, uint64_t *out_labels,
                ws_lake *lakes, size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured, const DeviceLists *dev = nullptr) {
   if (!c) return WS_ERR_BAD_ARG;
   size_t ph, pw;
+  const bool from_arrival = dev && dev->d_keys;
+  ws_options plain;
+  if (from_arrival) { plain = *opt; plain.edge_correction = 0; opt = &plain; }      // the plane as it stands
   int rc = check_plane(c, h, w, stride, opt, &ph, &pw);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n = ph * pw;
   const bool want_list = n_lakes != nullptr;
-  const uint8_t *d_img;
-  size_t d_stride;
-  const uint32_t *d_seeds;
-  if ((rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
+  const uint8_t *d_img = nullptr;
+  size_t d_stride = 0;
+  const uint32_t *d_seeds = nullptr;
+  if (!from_arrival && (rc = ensure(c, c->labels, (n ? n : 1) * sizeof(uint32_t)))) return rc;
   if (!dev && (rc = ensure(c, c->out64, (n ? n : 1) * sizeof(uint64_t)))) return rc;
   stats_begin(c);
-  if (dev) {
+  if (from_arrival) {
+    if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
+  } else if (dev) {
     if (n_seeds >= 0xFFFFFFFFull) return fail(c, WS_ERR_TOO_LARGE, "too many seeds");
     d_img = dev->d_img;
     d_stride = stride;
     if (opt->edge_correction && h * w == 0 && (rc = empty_image_block(c, &d_img, &d_stride, h, w))) return rc;
     if ((rc = shifted_seeds(c, dev->d_seeds_rc, n_seeds, opt, &d_seeds))) return rc;
   } else if ((rc = stage_inputs(c, img, h, w, stride, seeds_rc, n_seeds, opt, ph, pw, &d_img, &d_stride, &d_seeds))) return rc;
-  uint32_t *seg = (uint32_t *)c->labels.p;
+  const uint32_t *seg = from_arrival ? dev->d_seg : (const uint32_t *)c->labels.p;
   uint64_t *d_out64 = (uint64_t *)c->out64.p;
   // the flood itself is the segmenting one (same coloured set, same arrival stamps: lib.rs:1394-1438 == 1704-1748)
-  if ((rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, seg, opt->edge_correction != 0))) return rc;
-  const uint32_t *keys = (const uint32_t *)c->keys.p;
+  if (!from_arrival && (rc = run_fused(c, d_img, d_stride, (int)ph, (int)pw, opt->max_water_level, d_seeds, n_seeds, (uint32_t *)c->labels.p, opt->edge_correction != 0))) return rc;
+  const uint32_t *keys = from_arrival ? dev->d_keys : (const uint32_t *)c->keys.p;
   // every buffer first, so that nothing moves once launches (or captured graphs) hold its address
   if ((rc = ensure_uf(c, n_seeds + 1))) return rc;
   // Planes with a million colours and more (4096^2 random fields on) write their lake records from the list of the lakes
@@ -206,6 +214,7 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
   // (the fused-record mode follows from merging, want_list and cb == null)
   key.merging = merging; key.want_list = want_list; key.levels = levels; key.n_colours = n_seeds + 1; key.n = n; key.cap = cap;
   key.records = d_records;
+  key.keys = keys; key.seg = seg;
   key.generation = c->buffer_generation;
   const bool graph_able = !cb && c->stream != nullptr && !c->graph_unusable && !c->profiling && n != 0;
   bool use_graphs = graph_able && key == c->list_seen_key;
@@ -412,6 +421,27 @@ int ws_transform_to_list_device(ws_ctx *c, int merging, const uint8_t *d_img, si
     return fail(c, WS_ERR_BAD_ARG, "null pointer");
   const DeviceLists dev{d_img, d_seeds_rc, d_lakes};
   return merge_host(c, merging != 0, nullptr, h, w, stride, nullptr, n_seeds, opt, nullptr, nullptr, nullptr, nullptr, cap, n_lakes, offsets,
+                    uncoloured, &dev);
+}
+
+int ws_lists_from_arrival_device(ws_ctx *c, int merging, const uint32_t *d_keys, const uint32_t *d_seg_labels, size_t h, size_t w,
+                                 size_t n_seeds, const ws_options *opt, ws_lake *d_lakes, size_t cap, size_t *n_lakes, uint64_t *offsets,
+                                 uint64_t *uncoloured) {
+  if (int busy_rc = refuse_if_in_flight(c)) return busy_rc;
+  if (!c) return WS_ERR_BAD_ARG;
+  if (!opt || !n_lakes || !offsets || !uncoloured || (!d_lakes && cap) || ((!d_keys || !d_seg_labels) && h * w))
+    return fail(c, WS_ERR_BAD_ARG, "null pointer");
+  if (pick_engine(opt) == WS_ENGINE_SWEEP) return fail(c, WS_ERR_UNSUPPORTED, "the sweep engine keeps no arrival stamps");
+  if (int v = ws_options_validate(opt)) return fail(c, v, ws_strerror(v));
+  if (h * w == 0) {      // no pixel: no lake at any level
+    *n_lakes = 0;
+    for (uint32_t l = 0; l <= opt->max_water_level; ++l) { offsets[l] = 0; uncoloured[l] = 0; }
+    offsets[(size_t)opt->max_water_level + 1] = 0;
+    return WS_OK;
+  }
+  DeviceLists dev{nullptr, nullptr, d_lakes};
+  dev.d_keys = d_keys; dev.d_seg = d_seg_labels;
+  return merge_host(c, merging != 0, nullptr, h, w, w, nullptr, n_seeds, opt, nullptr, nullptr, nullptr, nullptr, cap, n_lakes, offsets,
                     uncoloured, &dev);
 }
 

@@ -99,7 +99,7 @@ struct Grow {      // a device buffer that only ever grows
 struct Rank {
   int rank = 0, device = 0;
   ws_ctx *ctx = nullptr;
-  Grow keys, labels, recv, rows, table, parent, img, seeds, colours, out64, cols;
+  Grow keys, labels, recv, rows, table, parent, img, seeds, colours, out64, cols, full_keys, full_labels;
   uint32_t *flag = nullptr;           // device: 4 words (the exchange loop's stop word; reduce scratch)
   uint32_t *flag_host = nullptr;      // pinned mirror
   // what the LOCAL exchange steps read from their neighbours (published before the barrier)
@@ -142,6 +142,11 @@ int gfail(ws_group *g, int code, const std::string &what) {
     const int rc_ = (call);                                                                                     \
     if (rc_ != WS_OK) return gfail((g), rc_, std::string("rank ") + std::to_string((rk).rank) + ": " + #call + ": " + ws_last_error((rk).ctx)); \
   } while (0)
+
+// the status of a ws_* call on a rank's own context, its message carried to the group (WS_ERR_CAPACITY included: the caller reads n_lakes)
+int gfail_if(ws_group *g, const Rank &rk, int rc) {
+  return rc == WS_OK ? WS_OK : gfail(g, rc, std::string("rank ") + std::to_string(rk.rank) + ": " + ws_last_error(rk.ctx));
+}
 
 int grow(ws_group *g, Grow &b, size_t bytes) {
   if (bytes <= b.cap) return WS_OK;
@@ -214,6 +219,42 @@ struct Exchange {
     if (left) G_HIP(g, hipMemcpyAsync(recv + 2 * w, local(nb[2])->pub_cols + h, h * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     if (right) G_HIP(g, hipMemcpyAsync(recv + 2 * w + h, local(nb[3])->pub_cols, h * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     G_HIP(g, hipStreamSynchronize(stream()));
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    return WS_OK;
+  }
+
+  // every rank's OWNED rows of a plane (`own`: its first owned row) -> rank 0's whole plane of field_h x w words (`full`, rank 0
+  // only): one message per rank and plane.  Returns with rank 0's copies complete.
+  int gather_rows(const uint32_t *own, size_t field_h, size_t w, uint32_t *full) {
+    size_t r0, r1, lo, hi;
+    if (ws_tile_rows(field_h, me.rank, g->world, &r0, &r1, &lo, &hi)) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row per rank");
+    if (g->is_rccl) {
+      RcclApi *n = rccl();
+      G_NCCL(g, n->GroupStart());
+      if (me.rank != 0) {
+        if (r1 > r0 && w) G_NCCL(g, n->Send(own, (r1 - r0) * w, ncclUint32, 0, g->comm, stream()));
+      } else {
+        for (int r = 1; r < g->world; ++r) {
+          size_t a, b, l2, h2;
+          (void)ws_tile_rows(field_h, r, g->world, &a, &b, &l2, &h2);
+          if (b > a && w) G_NCCL(g, n->Recv(full + a * w, (b - a) * w, ncclUint32, r, g->comm, stream()));
+        }
+      }
+      G_NCCL(g, n->GroupEnd());
+      if (me.rank == 0 && r1 > r0 && w) G_HIP(g, hipMemcpyAsync(full + r0 * w, own, (r1 - r0) * w * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+      G_HIP(g, hipStreamSynchronize(stream()));
+      return WS_OK;
+    }
+    me.pub_send = own;      // (every rank's plane is complete in memory: the steps before end with a wait for their stream)
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    if (me.rank == 0) {
+      for (int r = 0; r < g->world; ++r) {
+        size_t a, b, l2, h2;
+        (void)ws_tile_rows(field_h, r, g->world, &a, &b, &l2, &h2);
+        if (b > a && w) G_HIP(g, hipMemcpyAsync(full + a * w, local(r)->pub_send, (b - a) * w * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+      }
+      G_HIP(g, hipStreamSynchronize(stream()));
+    }
     if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
     return WS_OK;
   }
@@ -682,6 +723,64 @@ int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seed
   rc = for_local_ranks(g, [&](Rank &me) {
     const size_t i = (size_t)(me.rank - g->first_local);
     return tiled_rank(g, me, field_h, w, n_seeds_total, blocks[i], opt, merging, &rounds[i]);
+  });
+  if (exchange_rounds) *exchange_rounds = rounds[0];
+  return rc;
+}
+
+// transform_to_list (lib.rs:1551-1561 merging, 1837-1847 segmenting) of a field cut into row blocks: the flood -- the part that
+// scales with the pixels and needs the halo exchange -- runs on all ranks (tiled_rank), then every rank sends the arrival stamps
+// and segment labels of its owned rows to rank 0, whose context writes the lake records of all levels from the whole plane
+// (ws_lists_from_arrival_device: 8 B per pixel gathered, 20 B per pixel of workspace -- a 32768^2 field is 28 GiB of one
+// device's 288).  The lists are global objects (a lake spans blocks, its area is a sum over them); cutting the union-find
+// itself across ranks would trade this one gather for an exchange per level.
+int ws_transform_to_list_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seeds_total, const ws_tile_block *blocks,
+                                      const ws_options *opt, int merging, ws_lake *d_lakes, size_t cap, size_t *n_lakes,
+                                      uint64_t *offsets, uint64_t *uncoloured, uint32_t *exchange_rounds) {
+  int rc = check_group_call(g, opt);
+  if (rc) return rc;
+  if (!blocks || !n_lakes || !offsets || !uncoloured) return gfail(g, WS_ERR_BAD_ARG, "null pointer");
+  if (opt->edge_correction) return gfail(g, WS_ERR_UNSUPPORTED, "the tiled transforms take the field as it is: pad it first");
+  if (n_seeds_total >= 0x7FFFFFFFull) return gfail(g, WS_ERR_TOO_LARGE, "colours must stay below 2^31");
+  if (field_h < (size_t)g->world) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row per rank");
+  const bool root_here = g->first_local == 0;
+  if (root_here && !d_lakes && cap) return gfail(g, WS_ERR_BAD_ARG, "d_lakes is null");
+  for (size_t i = 0; i < g->ranks.size(); ++i) {
+    const ws_tile_block &b = blocks[i];
+    if (b.reserved != 0 || (field_h * w && (!b.d_img || !b.d_labels)) || (b.n_seeds && !b.d_seeds_rc))
+      return gfail(g, WS_ERR_BAD_ARG, "bad block descriptor");
+  }
+  *n_lakes = 0;
+  if (exchange_rounds) *exchange_rounds = 0;
+  std::vector<uint32_t> rounds(g->ranks.size(), 0);
+  rc = for_local_ranks(g, [&](Rank &me) -> int {
+    const size_t i = (size_t)(me.rank - g->first_local);
+    const ws_tile_block &b = blocks[i];
+    int rc2;
+    const uint32_t *keys, *labels;      // the rank's block: rows [lo, hi) of the field
+    size_t r0, r1, lo, hi;
+    if ((rc2 = ws_tile_rows(field_h, me.rank, g->world, &r0, &r1, &lo, &hi))) return gfail(g, rc2, "a field needs at least one row per rank");
+    if (g->world == 1) {
+      if ((rc2 = single_rank(g, me, field_h, w, b, opt, 0))) return rc2;
+      const uint32_t *k = nullptr; size_t kh = 0, kw = 0;
+      G_WS(g, me, ws_last_arrival_device(me.ctx, &k, &kh, &kw));
+      return gfail_if(g, me, ws_lists_from_arrival_device(me.ctx, merging, k, b.d_labels, field_h, w, n_seeds_total, opt, d_lakes, cap, n_lakes, offsets, uncoloured));
+    }
+    if ((rc2 = tiled_rank(g, me, field_h, w, n_seeds_total, b, opt, 0, &rounds[i]))) return rc2;
+    keys = (const uint32_t *)me.keys.p;
+    labels = b.d_labels;
+    Exchange x{g, me};
+    const size_t n = field_h * w;
+    if (me.rank == 0) {
+      if ((rc2 = grow(g, me.full_keys, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+      if ((rc2 = grow(g, me.full_labels, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+    }
+    G_HIP(g, hipStreamSynchronize(me.ctx->stream));
+    if ((rc2 = x.gather_rows(keys + (r0 - lo) * w, field_h, w, (uint32_t *)me.full_keys.p))) return rc2;
+    if ((rc2 = x.gather_rows(labels + (r0 - lo) * w, field_h, w, (uint32_t *)me.full_labels.p))) return rc2;
+    if (me.rank != 0) return WS_OK;
+    return gfail_if(g, me, ws_lists_from_arrival_device(me.ctx, merging, (const uint32_t *)me.full_keys.p, (const uint32_t *)me.full_labels.p, field_h, w,
+                                                        n_seeds_total, opt, d_lakes, cap, n_lakes, offsets, uncoloured));
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];
   return rc;

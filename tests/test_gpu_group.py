@@ -295,6 +295,117 @@ def test_tiled_device_8192_equals_single_domain(pkg, n_ranks):
     g.close()
 
 
+def _blocks_of(pkg, g, n_ranks, img, seeds, eng):
+    import torch
+    L, ffi = g.L, pkg._ffi
+    H, W = img.shape
+    rows = seeds[:, 0].contiguous()
+    blocks = (ffi.TileBlock * n_ranks)()
+    keep, spans = [], []
+    for r in range(n_ranks):
+        v = [ctypes.c_size_t() for _ in range(4)]
+        assert L.ws_tile_rows(H, r, n_ranks, *[ctypes.byref(x) for x in v]) == 0
+        r0, r1, lo, hi = (x.value for x in v)
+        b = torch.searchsorted(rows, torch.tensor([lo, hi], dtype=rows.dtype, device=rows.device))
+        i0, i1 = int(b[0]), int(b[1])
+        loc = seeds[i0:i1].clone()
+        loc[:, 0] -= lo
+        bi = img[lo:hi].contiguous()
+        lab = torch.empty((hi - lo, W), dtype=torch.int32, device=eng.device)
+        keep += [loc, bi, lab]
+        spans.append((r0, r1, lo, lab))
+        blocks[r] = ffi.TileBlock(bi.data_ptr(), loc.data_ptr() if i1 > i0 else None, None, i1 - i0, i0 + 1, 0, lab.data_ptr())
+    torch.cuda.synchronize()
+    return blocks, spans, keep
+
+
+@pytest.mark.parametrize("n_ranks,rccl", [(1, False), (2, False), (3, False), (4, False), (1, True)])
+@pytest.mark.parametrize("merging", [True, False])
+def test_transform_to_list_of_a_field_in_row_blocks(pkg, n_ranks, rccl, merging):
+    # ws_transform_to_list_tiled_device: the flood on all ranks, the stamps and labels of the owned rows gathered on rank 0, the
+    # records of every level from the whole plane there (ws_lists_from_arrival_device).  Lake sizes of every level against the
+    # oracle's (lib.rs:628-635), on a noise field and on a smooth one whose lakes span all blocks.
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    ffi = pkg._ffi
+    for kind in ("noise", "smooth"):
+        H, W = (300, 256) if kind == "noise" else (280, 192)
+        himg = cases.field(H, W, 31) if kind == "noise" else cases.smooth_field(H, W, 12, octaves=4)
+        hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.int64).reshape(-1, 2)
+        want = {}
+        run = ol.merge_arrival if merging else ol.segment      # (the segmenting oracle with a hook is the literal sweep form)
+        run(himg, hseeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)))
+        img = torch.from_numpy(himg).to(eng.device)
+        seeds = torch.from_numpy(hseeds.astype(np.int32)).to(eng.device)
+        g = Group(pkg, n_ranks, rccl=rccl)
+        blocks, spans, keep = _blocks_of(pkg, g, n_ranks, img, seeds, eng)
+        cap = 255 * (len(hseeds) + 1)      # every colour alive at every level: the most there can be
+        lakes = torch.zeros((cap, 2), dtype=torch.int64, device=eng.device)
+        n_lakes = ctypes.c_size_t(0)
+        offsets = np.zeros(256, dtype=np.uint64)
+        uncol = np.zeros(255, dtype=np.uint64)
+        opt = ffi.Options(254)
+        rounds = ctypes.c_uint32(0)
+        rc = g.L.ws_transform_to_list_tiled_device(g.h, H, W, len(hseeds), blocks, ctypes.byref(opt), int(merging), lakes.data_ptr(), cap, ctypes.byref(n_lakes),
+                                                   offsets.ctypes.data, uncol.ctypes.data, ctypes.byref(rounds))
+        assert rc == 0, (rc, g.err())
+        assert n_lakes.value == offsets[255] <= cap
+        rec = lakes.cpu().numpy()
+        for lvl in range(255):
+            dense = np.zeros(H * W + 1, dtype=np.uint64)
+            part = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+            dense[part[:, 0]] = part[:, 1].astype(np.uint64)
+            dense[0] = uncol[lvl]
+            assert (dense == want[lvl]).all(), (kind, lvl)
+        # the blocks hold the segmenting labels, as after ws_segment_tiled_device
+        seg = ol.segment_arrival(himg, hseeds)
+        for r0, r1, lo, lab in spans:
+            assert (lab[r0 - lo:r1 - lo].cpu().numpy().view(np.uint32) == seg[r0:r1]).all()
+        # a record buffer that is too small: the count is still reported
+        rc = g.L.ws_transform_to_list_tiled_device(g.h, H, W, len(hseeds), blocks, ctypes.byref(opt), int(merging), lakes.data_ptr(), 10, ctypes.byref(n_lakes),
+                                                   offsets.ctypes.data, uncol.ctypes.data, None)
+        assert rc == ffi.WS_ERR_CAPACITY and n_lakes.value == offsets[255] > 10
+        g.close()
+
+
+def test_lists_from_the_arrival_planes_of_a_finished_transform(pkg):
+    # ws_lists_from_arrival_device: transform_to_list without a second flood, from ws_last_arrival_device's stamps and the labels --
+    # the same records as ws_transform_to_list_device on image and seeds, merging and segmenting; a padded plane as it stands
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    ffi, L = pkg._ffi, pkg._ffi.lib()
+    for edge in (False, True):
+        himg = cases.field(210, 330, 8)
+        hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.int64).reshape(-1, 2)
+        img = torch.from_numpy(himg).to(eng.device)
+        seeds = torch.from_numpy(hseeds.astype(np.int32)).to(eng.device)
+        labels = eng.segment(img, seeds, edge=edge)
+        keys = eng.last_arrival().clone()
+        ph, pw = labels.shape
+        for merging in (1, 0):
+            cap = 255 * (len(hseeds) + 1)
+            a = torch.zeros((cap, 2), dtype=torch.int64, device=eng.device)
+            b = torch.zeros((cap, 2), dtype=torch.int64, device=eng.device)
+            na, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            oa, ob = np.zeros(256, dtype=np.uint64), np.zeros(256, dtype=np.uint64)
+            ua, ub = np.zeros(255, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+            opt = ffi.Options(254, int(edge))
+            assert L.ws_transform_to_list_device(eng.ctx.handle, merging, img.data_ptr(), 210, 330, 330, seeds.data_ptr(), len(hseeds), ctypes.byref(opt),
+                                                 a.data_ptr(), cap, ctypes.byref(na), oa.ctypes.data, ua.ctypes.data) == 0
+            assert L.ws_lists_from_arrival_device(eng.ctx.handle, merging, keys.data_ptr(), labels.data_ptr(), ph, pw, len(hseeds), ctypes.byref(opt),
+                                                  b.data_ptr(), cap, ctypes.byref(nb), ob.ctypes.data, ub.ctypes.data) == 0
+            assert na.value == nb.value and (oa == ob).all() and (ua == ub).all()
+            ra, rb = a[:na.value].cpu().numpy(), b[:nb.value].cpu().numpy()
+            for lvl in range(255):      # (the records of a level come in the order their lakes' waves wrote them)
+                pa, pb = ra[int(oa[lvl]):int(oa[lvl + 1])], rb[int(ob[lvl]):int(ob[lvl + 1])]
+                assert (pa[np.argsort(pa[:, 0])] == pb[np.argsort(pb[:, 0])]).all(), (edge, merging, lvl)
+    n0 = ctypes.c_size_t(5)
+    assert L.ws_lists_from_arrival_device(eng.ctx.handle, 1, None, None, 0, 7, 0, ctypes.byref(ffi.Options(254)), None, 0, ctypes.byref(n0), oa.ctypes.data, ua.ctypes.data) == 0
+    assert n0.value == 0 and not oa.any()
+
+
 def test_batch_group_equals_slice_by_slice(pkg):
     import torch
     dev = importlib.import_module("rustronomy_watershed_amd.device")
