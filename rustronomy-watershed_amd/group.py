@@ -119,6 +119,23 @@ class Group:
                                                        ctypes.byref(rounds)), "ws_segment_tiled_device")
         return rounds.value
 
+    def transform_to_list_tiled_device(self, field_rows, width, n_seeds_total, blocks, lakes, max_level=254, merging=True):
+        """transform_to_list of a field in row blocks (ws_transform_to_list_tiled_device): `blocks` as for segment_tiled_device,
+        `lakes` an int64 (cap, 2) tensor on rank 0's device for the (colour, area) records.  Returns (n_lakes, offsets numpy
+        (levels + 1), uncoloured numpy (levels), rounds) -- meaningful in the process that holds rank 0."""
+        import numpy as np
+        opt = _ffi.Options(max_level)
+        rounds = ctypes.c_uint32(0)
+        n = ctypes.c_size_t(0)
+        offsets = np.zeros(max_level + 2, dtype=np.uint64)
+        uncoloured = np.zeros(max_level + 1, dtype=np.uint64)
+        self._check(_ffi.lib().ws_transform_to_list_tiled_device(self._h, field_rows, width, n_seeds_total, blocks, ctypes.byref(opt), int(merging),
+                                                                 lakes.data_ptr() if lakes is not None and lakes.numel() else None,
+                                                                 lakes.shape[0] if lakes is not None else 0, ctypes.byref(n),
+                                                                 offsets.ctypes.data, uncoloured.ctypes.data, ctypes.byref(rounds)),
+                    "ws_transform_to_list_tiled_device")
+        return n.value, offsets, uncoloured, rounds.value
+
     # ---- one field in py x px tiles (both directions) ------------------------------------------------------------------------------
     @staticmethod
     def tile_grid(h, w, rank, py, px):
