@@ -295,6 +295,36 @@ def segment_tiled(block, rank, world, group=None, max_rounds=1 << 20):
     return block.labels[top:bot], rounds
 
 
+def gather_arrival_planes(block, rank, world, field_rows, group=None):
+    """After segment_tiled: every rank's OWNED rows of the arrival stamps and of the labels -> rank 0's whole planes (one message
+    per rank and plane; csrc/ws_tiled.hip: Exchange::gather_rows).  Returns (keys, labels) of field_rows x w on rank 0, None
+    elsewhere.  What transform_to_list of a tiled field reads (ws_transform_to_list_tiled_device: rank 0 then makes the lake
+    records of all levels from these two planes, ws_lists_from_arrival_device)."""
+    top = 1 if rank > 0 else 0
+    out = []
+    for plane in (block.keys, block.labels):
+        bot = plane.shape[0] - (1 if rank < world - 1 else 0)
+        mine = plane[top:bot].to(_comm_device(plane)).contiguous()
+        if world == 1:
+            out.append(mine)
+            continue
+        if rank == 0:
+            full = torch.empty((field_rows, plane.shape[1]), dtype=plane.dtype, device=mine.device)
+            full[: mine.shape[0]] = mine
+            for r in range(1, world):
+                r0, r1, _, _ = row_block(field_rows, r, world)
+                if r1 > r0:
+                    part = torch.empty((r1 - r0, plane.shape[1]), dtype=plane.dtype, device=mine.device)
+                    dist.recv(part, src=r, group=group)
+                    full[r0:r1] = part
+            out.append(full)
+        else:
+            if mine.shape[0]:
+                dist.send(mine, dst=0, group=group)
+            out.append(None)
+    return (out[0], out[1]) if rank == 0 else None
+
+
 # ---- the field cut in both directions (csrc/ws_tiled.hip: tiled2d_rank) ---------------------------------------------------------
 
 def tile_grid(height, width, rank, py, px):

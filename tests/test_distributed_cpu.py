@@ -46,6 +46,46 @@ def _tiled_worker(rank, world, port, img, seeds, max_level, outdir, force_genera
         dist.destroy_process_group()
 
 
+def _arrival_worker(rank, world, port, img, seeds, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        ge.load_package()
+        wd = importlib.import_module("rustronomy_watershed_amd.distributed")
+        from numpy_engine import NumpyBlockEngine
+        r0, r1, lo, hi = wd.row_block(img.shape[0], rank, world)
+        loc, col = wd.local_seeds(seeds.astype(np.int64), lo, hi)
+        block = NumpyBlockEngine(img[lo:hi], loc.numpy(), col.numpy(), 254)
+        wd.segment_tiled(block, rank, world)
+        planes = wd.gather_arrival_planes(block, rank, world, img.shape[0])
+        assert (planes is not None) == (rank == 0)
+        if rank == 0:
+            np.save(os.path.join(outdir, "keys.npy"), planes[0].numpy().view(np.uint32))
+            np.save(os.path.join(outdir, "labels.npy"), planes[1].numpy().view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_arrival_planes_gathered_on_rank_0_are_the_single_domain_planes(world):
+    # transform_to_list of a tiled field (ws_transform_to_list_tiled_device) makes its lake records on rank 0 from the gathered
+    # arrival stamps and labels of every rank's owned rows: here the gather over gloo, against the oracle's planes of the whole field
+    img = cases.smooth_field(57, 44, 6)
+    seeds = np.asarray(ol.find_local_minima(img), dtype=np.uint64).reshape(-1, 2)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_arrival_worker, args=(world, _free_port(), img, seeds, d), nprocs=world, join=True)
+        keys, labels = np.load(os.path.join(d, "keys.npy")), np.load(os.path.join(d, "labels.npy"))
+    want_labels, want_keys = ol.segment_arrival(img, seeds, want_keys=True)
+    assert (labels == want_labels).all()
+    # the oracle's stamps are (level << 32 | ring) in 64 bits, ~0 where no flood arrives; the engine's (level << 24 | ring) in 32
+    # bits, level 255 and up for "never" (csrc/ws_common.hpp: KEY_INF)
+    never = want_keys == np.uint64(0xFFFFFFFFFFFFFFFF)
+    packed = ((want_keys >> np.uint64(32)) << np.uint64(24)) | (want_keys & np.uint64(0xFFFFFF))
+    assert (keys[~never] == packed[~never]).all() and (keys[never] >= 0xFF000000).all()
+
+
 def _run_tiled(img, seeds, world, max_level=254, force_general=False):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_tiled_worker, args=(world, _free_port(), img, np.asarray(seeds, dtype=np.uint64).reshape(-1, 2), max_level, d, force_general),
