@@ -369,6 +369,56 @@ def test_transform_to_list_of_a_field_in_row_blocks(pkg, n_ranks, rccl, merging)
         g.close()
 
 
+def test_transform_to_list_of_a_field_in_row_blocks_with_any_seed_list(pkg):
+    # the general form of the tiled transform (a list in any order: explicit colours per block) under the lists
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    ffi = pkg._ffi
+    H, W, n_ranks = 150, 131, 3
+    himg = cases.field(H, W, 77)
+    rng = np.random.default_rng(4)
+    hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.int64).reshape(-1, 2)
+    hseeds = hseeds[rng.permutation(len(hseeds))][: len(hseeds) // 2]
+    want = {}
+    ol.merge_arrival(himg, hseeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)))
+    img = torch.from_numpy(himg).to(eng.device)
+    g = Group(pkg, n_ranks)
+    blocks = (ffi.TileBlock * n_ranks)()
+    keep = []
+    for r in range(n_ranks):
+        v = [ctypes.c_size_t() for _ in range(4)]
+        assert g.L.ws_tile_rows(H, r, n_ranks, *[ctypes.byref(x) for x in v]) == 0
+        r0, r1, lo, hi = (x.value for x in v)
+        inside = (hseeds[:, 0] >= lo) & (hseeds[:, 0] < hi)
+        loc = hseeds[inside].copy()
+        loc[:, 0] -= lo
+        col = (np.nonzero(inside)[0] + 1).astype(np.int32)
+        t_loc = torch.from_numpy(loc.astype(np.int32)).to(eng.device).contiguous()
+        t_col = torch.from_numpy(col).to(eng.device).contiguous()
+        bi = img[lo:hi].contiguous()
+        lab = torch.empty((hi - lo, W), dtype=torch.int32, device=eng.device)
+        keep += [t_loc, t_col, bi, lab]
+        blocks[r] = ffi.TileBlock(bi.data_ptr(), t_loc.data_ptr(), t_col.data_ptr(), len(loc), 0, 0, lab.data_ptr())
+    torch.cuda.synchronize()
+    cap = 255 * (len(hseeds) + 1)
+    lakes = torch.zeros((cap, 2), dtype=torch.int64, device=eng.device)
+    n_lakes = ctypes.c_size_t(0)
+    offsets, uncol = np.zeros(256, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+    opt = ffi.Options(254)
+    rc = g.L.ws_transform_to_list_tiled_device(g.h, H, W, len(hseeds), blocks, ctypes.byref(opt), 1, lakes.data_ptr(), cap, ctypes.byref(n_lakes),
+                                               offsets.ctypes.data, uncol.ctypes.data, None)
+    assert rc == 0, (rc, g.err())
+    rec = lakes.cpu().numpy()
+    for lvl in range(255):
+        dense = np.zeros(H * W + 1, dtype=np.uint64)
+        part = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+        dense[part[:, 0]] = part[:, 1].astype(np.uint64)
+        dense[0] = uncol[lvl]
+        assert (dense == want[lvl]).all(), lvl
+    g.close()
+
+
 def test_lists_from_the_arrival_planes_of_a_finished_transform(pkg):
     # ws_lists_from_arrival_device: transform_to_list without a second flood, from ws_last_arrival_device's stamps and the labels --
     # the same records as ws_transform_to_list_device on image and seeds, merging and segmenting; a padded plane as it stands
