@@ -490,6 +490,13 @@ int ws_segment_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seed
 int ws_transform_to_list_tiled_device(ws_group *g, size_t field_h, size_t w, size_t n_seeds_total, const ws_tile_block *blocks,
                                       const ws_options *opt, int merging, ws_lake *d_lakes, size_t cap, size_t *n_lakes,
                                       uint64_t *offsets, uint64_t *uncoloured, uint32_t *exchange_rounds);
+/* ... and with host buffers, as ws_segment_tiled takes them (edge correction by padding: the lists are those of the padded
+ * plane, as ws_transform_to_list's): every rank uploads its rows, the records come back from rank 0's device into `lakes`
+ * (cap records; WS_ERR_CAPACITY with the count in *n_lakes when that is too few).  What a Rust caller of transform_to_list gets
+ * from several GPUs. */
+int ws_transform_to_list_tiled(ws_group *g, int merging, const uint8_t *img, size_t h, size_t w, size_t row_stride,
+                               const uint64_t *seeds_rc, size_t n_seeds, const ws_options *opt, ws_lake *lakes, size_t cap,
+                               size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured, uint32_t *exchange_rounds);
 
 /* The field cut in BOTH directions (BASELINE config 5's "2-D tiles"): py x px tiles, rank = ty * px + tx, py * px = the
  * group's ranks.  ws_tile_grid: rows[4] = {r0, r1, lo, hi} and cols[4] = {c0, c1, clo, chi} of a rank's tile -- owned

@@ -249,6 +249,9 @@ extern "C" {
         n_seeds: usize, opt: *const ws_options, merging: c_int, out_labels: *mut u64, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block,
         opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_transform_to_list_tiled(g: *mut ws_group, merging: c_int, img: *const u8, h: usize, w: usize, row_stride: usize, seeds_rc: *const u64, n_seeds: usize,
+                                      opt: *const ws_options, lakes: *mut ws_lake, cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64,
+                                      exchange_rounds: *mut u32) -> c_int;
     pub fn ws_transform_to_list_tiled_device(g: *mut ws_group, field_h: usize, w: usize, n_seeds_total: usize, blocks: *const ws_tile_block, opt: *const ws_options,
                                              merging: c_int, d_lakes: *mut ws_lake, cap: usize, n_lakes: *mut usize, offsets: *mut u64, uncoloured: *mut u64,
                                              exchange_rounds: *mut u32) -> c_int;

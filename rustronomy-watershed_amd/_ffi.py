@@ -157,6 +157,7 @@ SIGNATURES = {
     "ws_tile_rows": (ctypes.c_int, [sz, ctypes.c_int, ctypes.c_int, szp, szp, szp, szp]),
     "ws_segment_tiled": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, vp, u32p]),
     "ws_segment_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, ctypes.POINTER(TileBlock), ctypes.POINTER(Options), ctypes.c_int, u32p]),
+    "ws_transform_to_list_tiled": (ctypes.c_int, [vp, ctypes.c_int, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), vp, sz, szp, vp, vp, u32p]),
     "ws_transform_to_list_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, vp, ctypes.POINTER(Options), ctypes.c_int, vp, sz, szp, vp, vp, u32p]),
     "ws_tile_grid": (ctypes.c_int, [sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, szp, szp]),
     "ws_segment_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(TileBlock2D), ctypes.POINTER(Options), ctypes.c_int, u32p]),

@@ -823,13 +823,21 @@ int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int p
 // every rank ONE contiguous range, found by binary search; any other list is dealt out seed by seed with explicit colours
 // (the general form).  With edge correction the rank's rows of the PADDED plane are built on the device: a zeroed block and
 // a 2-D copy of the image rows that fall into it, one column in.
-int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc, size_t n_seeds,
-                     const ws_options *opt, int merging, uint64_t *out_labels, uint32_t *exchange_rounds) {
+// the lake records of transform_to_list, wanted from a host-buffer tiled call (ws_transform_to_list_tiled)
+struct HostLists {
+  ws_lake *lakes;
+  size_t cap;
+  size_t *n_lakes;
+  uint64_t *offsets, *uncoloured;
+};
+
+static int segment_tiled_host(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc, size_t n_seeds,
+                              const ws_options *opt, int merging, uint64_t *out_labels, uint32_t *exchange_rounds, const HostLists *lists) {
   int rc = check_group_call(g, opt);
   if (rc) return rc;
   if ((!img && h * w) || (!seeds_rc && n_seeds) || stride < w) return gfail(g, WS_ERR_BAD_ARG, "bad argument");
   const size_t e = opt->edge_correction ? 2 : 0, ph = h + e, pw = w + e, shift = opt->edge_correction && opt->seed_shift ? 1 : 0;
-  if (!out_labels && ph * pw) return gfail(g, WS_ERR_BAD_ARG, "out_labels is null");
+  if (!lists && !out_labels && ph * pw) return gfail(g, WS_ERR_BAD_ARG, "out_labels is null");
   if (n_seeds >= 0x7FFFFFFFull) return gfail(g, WS_ERR_TOO_LARGE, "too many seeds");
   if (ph > 0x7FFFFFF0ull || pw > 0x7FFFFFF0ull) return gfail(g, WS_ERR_TOO_LARGE, "plane too large");
   if (exchange_rounds) *exchange_rounds = 0;
@@ -900,9 +908,37 @@ int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t
     b.first_colour = first_colour;
     b.d_labels = (uint32_t *)me.labels.p;
     const size_t i = (size_t)(me.rank - g->first_local);
-    if (world == 1) rc2 = single_rank(g, me, ph, pw, b, &plain, merging);
-    else rc2 = tiled_rank(g, me, ph, pw, n_seeds, b, &plain, merging, &rounds[i]);
+    if (world == 1) rc2 = single_rank(g, me, ph, pw, b, &plain, lists ? 0 : merging);
+    else rc2 = tiled_rank(g, me, ph, pw, n_seeds, b, &plain, lists ? 0 : merging, &rounds[i]);
     if (rc2) return rc2;
+    if (lists) {      // transform_to_list: the arrival planes of the owned rows to rank 0, the records of all levels there (see the device form)
+      const uint32_t *keys = (const uint32_t *)me.keys.p, *full_k = keys, *full_l = b.d_labels;
+      if (world == 1) {
+        size_t kh = 0, kw = 0;
+        G_WS(g, me, ws_last_arrival_device(me.ctx, &full_k, &kh, &kw));
+      } else {
+        Exchange x{g, me};
+        const size_t n = ph * pw;
+        if (me.rank == 0) {
+          if ((rc2 = grow(g, me.full_keys, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+          if ((rc2 = grow(g, me.full_labels, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+        }
+        G_HIP(g, hipStreamSynchronize(s));
+        if ((rc2 = x.gather_rows(keys + (r0 - lo) * pw, ph, pw, (uint32_t *)me.full_keys.p))) return rc2;
+        if ((rc2 = x.gather_rows(b.d_labels + (r0 - lo) * pw, ph, pw, (uint32_t *)me.full_labels.p))) return rc2;
+        full_k = (const uint32_t *)me.full_keys.p;
+        full_l = (const uint32_t *)me.full_labels.p;
+      }
+      if (me.rank != 0) return WS_OK;
+      if ((rc2 = grow(g, me.out64, std::max<size_t>(lists->cap, 1) * sizeof(ws_lake)))) return rc2;
+      rc2 = ws_lists_from_arrival_device(me.ctx, merging, full_k, full_l, ph, pw, n_seeds, &plain, (ws_lake *)me.out64.p, lists->cap, lists->n_lakes,
+                                         lists->offsets, lists->uncoloured);
+      if (rc2 != WS_OK && rc2 != WS_ERR_CAPACITY) return gfail_if(g, me, rc2);
+      const size_t got = std::min(*lists->n_lakes, lists->cap);
+      if (got) G_HIP(g, hipMemcpyAsync(lists->lakes, me.out64.p, got * sizeof(ws_lake), hipMemcpyDeviceToHost, s));
+      G_HIP(g, hipStreamSynchronize(s));
+      return gfail_if(g, me, rc2);
+    }
     // ---- the rows it owns, widened, into the caller's plane
     const size_t own = (r1 - r0) * pw;
     // (as u32 chunks over the rank's own link, widened by host threads of the rank's context: ws_hostcopy.hip)
@@ -911,6 +947,23 @@ int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];
   return rc;
+}
+
+int ws_segment_tiled(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc, size_t n_seeds,
+                     const ws_options *opt, int merging, uint64_t *out_labels, uint32_t *exchange_rounds) {
+  return segment_tiled_host(g, img, h, w, stride, seeds_rc, n_seeds, opt, merging, out_labels, exchange_rounds, nullptr);
+}
+
+// transform_to_list of a host field over the ranks of the group: as ws_segment_tiled up to the flood, then as
+// ws_transform_to_list_tiled_device; the records go to the caller's host buffer from rank 0's device.
+int ws_transform_to_list_tiled(ws_group *g, int merging, const uint8_t *img, size_t h, size_t w, size_t stride, const uint64_t *seeds_rc,
+                               size_t n_seeds, const ws_options *opt, ws_lake *lakes, size_t cap, size_t *n_lakes, uint64_t *offsets,
+                               uint64_t *uncoloured, uint32_t *exchange_rounds) {
+  if (!g) return WS_ERR_BAD_ARG;
+  if (!n_lakes || !offsets || !uncoloured || (!lakes && cap)) return gfail(g, WS_ERR_BAD_ARG, "null pointer");
+  *n_lakes = 0;
+  const HostLists lists{lakes, cap, n_lakes, offsets, uncoloured};
+  return segment_tiled_host(g, img, h, w, stride, seeds_rc, n_seeds, opt, merging, nullptr, exchange_rounds, &lists);
 }
 
 // ... in py x px tiles: every local rank uploads its tile of the (padded) image, takes the seeds that fall on its plane with

@@ -1,6 +1,7 @@
 // C++ host-side mirror (include/ws_watershed.hpp) exercised the way the reference's README
 // quickstart and unit tests use the Rust API.  `test_mirror cpu` needs no GPU; `test_mirror gpu`
 // runs the quickstart on device 0 and checks it against the CPU oracle (test infrastructure).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -295,6 +296,29 @@ static int group_sequence_checks() {
     CHECK(oute == wante);
     CHECK(ws_segment_tiled2d(g4, img.data(), H, W, W, rc_pairs.data(), n, &o2, 3, 2, 0, oute.data(), nullptr) == WS_ERR_BAD_ARG);
     ws_group_destroy(g4);
+  }
+  // transform_to_list of the field over the group against the one-context call: the same lakes and areas at every level
+  {
+    ws_options o3;
+    ws_options_default(&o3);
+    const size_t cap = 255 * (n + 1);
+    std::vector<ws_lake> la(cap), lb(cap);
+    std::vector<uint64_t> oa(256), ob(256), ua(255), ub(255);
+    size_t na = 0, nb = 0;
+    ws_ctx *c1 = nullptr;
+    CHECK(ws_ctx_create(0, &c1) == WS_OK);
+    CHECK(ws_transform_to_list(c1, 1, img.data(), H, W, W, rc_pairs.data(), n, &o3, la.data(), cap, &na, oa.data(), ua.data()) == WS_OK);
+    CHECK(ws_transform_to_list_tiled(g, 1, img.data(), H, W, W, rc_pairs.data(), n, &o3, lb.data(), cap, &nb, ob.data(), ub.data(), nullptr) == WS_OK);
+    CHECK(na == nb && oa == ob && ua == ub);
+    auto by_colour = [](const ws_lake &x, const ws_lake &y) { return x.colour < y.colour; };
+    for (size_t l = 0; l < 255; ++l) {      // (a level's records come in the order their waves wrote them)
+      std::sort(la.begin() + oa[l], la.begin() + oa[l + 1], by_colour);
+      std::sort(lb.begin() + ob[l], lb.begin() + ob[l + 1], by_colour);
+    }
+    bool same = true;
+    for (size_t i = 0; i < na; ++i) same = same && la[i].colour == lb[i].colour && la[i].area == lb[i].area;
+    CHECK(same);
+    ws_ctx_destroy(c1);
   }
   const uint64_t bad[2] = {H, 0};
   CHECK(ws_segment_tiled(g, img.data(), H, W, W, bad, 1, &o, 0, out.data(), nullptr) == WS_ERR_SEED_OOB);

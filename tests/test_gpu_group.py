@@ -419,6 +419,45 @@ def test_transform_to_list_of_a_field_in_row_blocks_with_any_seed_list(pkg):
     g.close()
 
 
+@pytest.mark.parametrize("n_ranks", [1, 2, 4])
+@pytest.mark.parametrize("edge", [False, True])
+def test_transform_to_list_of_a_host_field_over_a_group(pkg, n_ranks, edge):
+    # ws_transform_to_list_tiled: host image and (usize, usize) seeds in, lake records out -- what a Rust caller of transform_to_list
+    # (lib.rs:1551-1561) gets from several GPUs.  Every level's lake sizes against the oracle's, with edge correction (the padded
+    # plane's lists, as ws_transform_to_list's), a list in any order, and a record buffer that is too small.
+    ffi = pkg._ffi
+    rng = np.random.default_rng(n_ranks)
+    himg = cases.field(97, 120, 5)
+    hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.uint64).reshape(-1, 2)
+    g = Group(pkg, n_ranks)
+    for lists in (hseeds, hseeds[rng.permutation(len(hseeds))][: len(hseeds) // 3]):
+        lists = np.ascontiguousarray(lists)
+        for merging in (1, 0):
+            want = {}
+            (ol.merge_arrival if merging else ol.segment)(himg, lists, edge=edge, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)))
+            cap = 255 * (len(lists) + 1)
+            rec = np.zeros((cap, 2), dtype=np.uint64)
+            n_lakes = ctypes.c_size_t(0)
+            offsets, uncol = np.zeros(256, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+            opt = ffi.Options(254, int(edge))
+            rc = g.L.ws_transform_to_list_tiled(g.h, merging, himg.ctypes.data, 97, 120, 120, lists.ctypes.data, len(lists), ctypes.byref(opt),
+                                                rec.ctypes.data, cap, ctypes.byref(n_lakes), offsets.ctypes.data, uncol.ctypes.data, None)
+            assert rc == 0, (rc, g.err())
+            e = 2 if edge else 0
+            npx = (97 + e) * (120 + e)
+            for lvl in range(255):
+                dense = np.zeros(npx + 1, dtype=np.uint64)
+                part = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+                dense[part[:, 0].astype(np.int64)] = part[:, 1]
+                dense[0] = uncol[lvl]
+                assert (dense == want[lvl]).all(), (merging, lvl)
+            total = n_lakes.value
+            rc = g.L.ws_transform_to_list_tiled(g.h, merging, himg.ctypes.data, 97, 120, 120, lists.ctypes.data, len(lists), ctypes.byref(opt),
+                                                rec.ctypes.data, 7, ctypes.byref(n_lakes), offsets.ctypes.data, uncol.ctypes.data, None)
+            assert rc == ffi.WS_ERR_CAPACITY and n_lakes.value == total
+    g.close()
+
+
 def test_lists_from_the_arrival_planes_of_a_finished_transform(pkg):
     # ws_lists_from_arrival_device: transform_to_list without a second flood, from ws_last_arrival_device's stamps and the labels --
     # the same records as ws_transform_to_list_device on image and seeds, merging and segmenting; a padded plane as it stands
