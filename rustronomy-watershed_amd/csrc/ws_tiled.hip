@@ -700,6 +700,32 @@ int ws_group_selftest(ws_group *g) {
     for (int k = 0; k < world; ++k)
       for (size_t i = 0; i < w; ++i)
         if (got[(size_t)k * w + i] != (uint32_t)k * 100000u + (uint32_t)(w + i)) return gfail(g, g->is_rccl ? WS_ERR_RCCL : WS_ERR_HIP, "selftest: all-gather delivered wrong words");
+    // the gather of owned rows on rank 0 (transform_to_list of a tiled field): a field of 2 * world + 1 rows, every rank's owned
+    // rows hold rank * 100000 + field row * w + column
+    {
+      const size_t fh = 2 * (size_t)world + 1;
+      size_t r0, r1, lo, hi;
+      if (ws_tile_rows(fh, me.rank, world, &r0, &r1, &lo, &hi)) return gfail(g, WS_ERR_BAD_ARG, "selftest: tile rows");
+      std::vector<uint32_t> own((r1 - r0) * w), full(fh * w);
+      for (size_t r = r0; r < r1; ++r)
+        for (size_t i = 0; i < w; ++i) own[(r - r0) * w + i] = (uint32_t)me.rank * 100000u + (uint32_t)(r * w + i);
+      if ((rc = grow(g, me.rows, std::max<size_t>(own.size(), 1) * sizeof(uint32_t)))) return rc;
+      if (me.rank == 0 && (rc = grow(g, me.full_keys, fh * w * sizeof(uint32_t)))) return rc;
+      G_HIP(g, hipMemcpyAsync(me.rows.p, own.data(), own.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+      G_HIP(g, hipStreamSynchronize(s));
+      if ((rc = x.gather_rows((const uint32_t *)me.rows.p, fh, w, (uint32_t *)me.full_keys.p))) return rc;
+      if (me.rank == 0) {
+        G_HIP(g, hipMemcpyAsync(full.data(), me.full_keys.p, fh * w * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        G_HIP(g, hipStreamSynchronize(s));
+        for (int k = 0; k < world; ++k) {
+          size_t a, b, l2, h2;
+          (void)ws_tile_rows(fh, k, world, &a, &b, &l2, &h2);
+          for (size_t r = a; r < b; ++r)
+            for (size_t i = 0; i < w; ++i)
+              if (full[r * w + i] != (uint32_t)k * 100000u + (uint32_t)(r * w + i)) return gfail(g, g->is_rccl ? WS_ERR_RCCL : WS_ERR_HIP, "selftest: the gather of owned rows on rank 0 delivered wrong words");
+        }
+      }
+    }
     return WS_OK;
   });
 }
