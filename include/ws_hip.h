@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 3 /* 2: ws_options grew to 8 bytes (seed_shift); 3: ws_group_* / ws_*_tiled / ws_segment_batch_group, WS_ERR_RCCL */
+#define WS_ABI_VERSION 3 /* 2: ws_options grew to 8 bytes (seed_shift); 3: ws_group_* / ws_*_tiled* / ws_segment_batch* / ws_segment_minima* / ws_lists_from_arrival_device / ws_ctx_set_host_threads, WS_ERR_RCCL */
 
 /* lib.rs:138-141 */
 #define WS_UNCOLOURED 0u
