@@ -167,6 +167,7 @@ hipError_t minima_write(hipStream_t s, const uint8_t *nibbles, int h, int w, con
                         uint32_t *mask = nullptr, uint32_t *word_base = nullptr,      // w % 32 == 0: the seed tables of this list (seed_tables' layout)
                         uint32_t *zero_a = nullptr, size_t n_zero_a = 0, uint32_t *zero_b = nullptr, size_t n_zero_b = 0);
 hipError_t widen_pairs(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t n_values);
+hipError_t narrow_words(hipStream_t s, const uint64_t *src, uint32_t *dst, size_t n);      // 64-bit words known to fit 32 bits
 
 inline int tiles_of(int n) { return (n + TS - 1) / TS; }
 

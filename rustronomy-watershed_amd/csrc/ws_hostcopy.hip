@@ -94,18 +94,23 @@ static int host_copy_slots(ws_ctx *c) {
 }
 
 // the plane widened on the device and copied whole (small planes, no host threads)
-static int one_copy(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n) {
+static int one_copy(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t st) {
+  // (callers that park their u32 words in the context's u64 buffer must keep to the chunked road -- host_copy_in_chunks: this
+  // path widens INTO that buffer and may reallocate it)
+  if (c->out64.p && (const char *)d_labels >= (const char *)c->out64.p && (const char *)d_labels < (const char *)c->out64.p + c->out64.cap)
+    return fail(c, WS_ERR_BAD_ARG, "internal: the words to widen sit in the buffer they would be widened into");
   int rc = ensure(c, c->out64, std::max<size_t>(n, 1) * sizeof(uint64_t));
   if (rc) return rc;
-  HIP_TRY(c, widen_labels(c->stream, d_labels, (uint64_t *)c->out64.p, n));
-  HIP_TRY(c, hipMemcpyAsync(out, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, widen_labels(st, d_labels, (uint64_t *)c->out64.p, n));
+  HIP_TRY(c, hipMemcpyAsync(out, c->out64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
   return WS_OK;
 }
 
-int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n) {
+int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t on) {
+  const hipStream_t st = on ? on : c->stream;
   const int T = host_threads(c);
-  if (!host_copy_in_chunks(c, n)) return one_copy(c, d_labels, out, n);
+  if (!host_copy_in_chunks(c, n)) return one_copy(c, d_labels, out, n, st);
   if (int rc = host_copy_slots(c)) return rc;
   const size_t HC_CHUNK = chunk_of(n);
   const size_t nch = (n + HC_CHUNK - 1) / HC_CHUNK;
@@ -135,8 +140,8 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
     // the calling thread widens by itself, chunk after chunk (not one_copy: the source may live in the context's u64 buffer)
     for (size_t i = 0; i < nch; ++i) {
       const size_t len = std::min(HC_CHUNK, n - i * HC_CHUNK);
-      HIP_TRY(c, hipMemcpyAsync(stage, d_labels + i * HC_CHUNK, len * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipMemcpyAsync(stage, d_labels + i * HC_CHUNK, len * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipStreamSynchronize(st));
       widen_span(stage, out + i * HC_CHUNK, len);
     }
     return WS_OK;
@@ -148,8 +153,8 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
     while (issued < nch && issued - freed < (size_t)HC_SLOTS && err == hipSuccess) {
       const size_t len = std::min(HC_CHUNK, n - issued * HC_CHUNK);
       err = hipMemcpyAsync(stage + (issued % HC_SLOTS) * HC_CHUNK, d_labels + issued * HC_CHUNK, len * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, c->stream);
-      if (err == hipSuccess) err = hipEventRecord(c->hc_ev[issued % HC_SLOTS], c->stream);
+                           hipMemcpyDeviceToHost, st);
+      if (err == hipSuccess) err = hipEventRecord(c->hc_ev[issued % HC_SLOTS], st);
       ++issued;
     }
     if (err != hipSuccess) break;
@@ -164,7 +169,7 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
   if (err != hipSuccess) abort.store(true);
   for (auto &th : pool) th.join();
   if (err != hipSuccess) {
-    (void)hipStreamSynchronize(c->stream);      // no copy may still be writing a slot when the context goes on
+    (void)hipStreamSynchronize(st);      // no copy may still be writing a slot when the context goes on
     HIP_TRY(c, err);
   }
   return WS_OK;

@@ -524,6 +524,21 @@ hipError_t widen_pairs(hipStream_t s, const uint32_t *src, uint64_t *dst, size_t
   return widen_labels(s, src, dst, n_values);
 }
 
+// ... and back: 64-bit words that are known to fit 32 bits (lake records: a colour and an area of a plane below 2^31 pixels), so
+// that they cross the bus as half the bytes and are widened again by the host's threads (ws_hostcopy.hip)
+__global__ void k_narrow_words(const uint64_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) dst[i] = (uint32_t)src[i];
+}
+
+hipError_t narrow_words(hipStream_t s, const uint64_t *src, uint32_t *dst, size_t n) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 1023) / 1024 < 8192 ? (n + 1023) / 1024 : 8192);
+  k_narrow_words<<<blocks, 256, 0, s>>>(src, dst, n);
+  return hipGetLastError();
+}
+
 // Label plane as the reference's hook sees it after `level` (lib.rs:1796-1804): a pixel
 // is coloured once its arrival level is <= level; segmenting colours never change later.
 __global__ void k_snapshot(const uint32_t *keys, const uint32_t *labels, uint64_t *dst, size_t n,

@@ -282,8 +282,22 @@ int merge_host(ws_ctx *c, bool merging, const uint8_t *img, size_t h, size_t w, 
       for (uint32_t l = g0; l < g1; ++l) offsets[l + 1] += offsets[l];      // counts -> offsets
       const size_t end = std::min<size_t>(offsets[g1], cap);
       if (!dev && end > copied) {
-        HIP_TRY(c, hipMemcpyAsync(lakes + copied, (const ws_lake *)c->lakes.p + copied, (end - copied) * sizeof(ws_lake), hipMemcpyDeviceToHost, c->copy_stream));
-        copied = end;
+        // A group of two million records and more (2048^2 planes on) crosses the bus as u32 -- a colour and an area of a plane below
+        // 2^31 pixels fit -- and is widened into the caller's records by the host's threads while later levels are computed
+        // (ws_hostcopy.hip; pieces of at most n records: the narrowed words borrow the u64 label buffer, n x 8 bytes).
+        // A piece that is too short for the chunked road must NOT go down it: labels_to_host_u64's other path widens into the very
+        // buffer the narrowed words sit in (and may reallocate it).  Such pieces are copied as they are.
+        const bool may_narrow = n < 0x80000000ull && c->out64.p && c->out64.cap >= n * sizeof(uint64_t);
+        while (copied < end) {
+          const size_t piece = std::min<size_t>(end - copied, n);
+          if (may_narrow && 2 * piece >= ((size_t)1 << 22) && host_copy_in_chunks(c, 2 * piece)) {      // (from 2 M records a piece: below, starting the threads costs what they save -- 1024^2: 4.5 against 4.1 ms)
+            HIP_TRY(c, narrow_words(c->copy_stream, (const uint64_t *)((const ws_lake *)c->lakes.p + copied), (uint32_t *)c->out64.p, 2 * piece));
+            if ((rc = labels_to_host_u64(c, (const uint32_t *)c->out64.p, (uint64_t *)(lakes + copied), 2 * piece, c->copy_stream))) return rc;
+          } else {
+            HIP_TRY(c, hipMemcpyAsync(lakes + copied, (const ws_lake *)c->lakes.p + copied, piece * sizeof(ws_lake), hipMemcpyDeviceToHost, c->copy_stream));
+          }
+          copied += piece;
+        }
       }
     }
     HIP_TRY(c, hipStreamSynchronize(c->copy_stream));

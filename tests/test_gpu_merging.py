@@ -315,3 +315,43 @@ def test_transform_to_list_device_resident(pkg):
                 r = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
                 nz = np.nonzero(w[1:])[0] + 1
                 assert unc[lvl] == w[0] and (np.sort(r[:, 0]) == nz).all() and (r[np.argsort(r[:, 0]), 1] == w[nz]).all(), (shape, lvl, rep)
+
+
+def test_host_lists_of_a_plane_whose_records_cross_the_bus_as_u32(pkg):
+    # ws_transform_to_list with host buffers at 2048^2 (39 M records, 2.4 M a group of levels): groups of two million words and
+    # more are narrowed to u32 on the device and widened into the caller's ws_lake records by the host's threads (ws_lists.hip,
+    # ws_hostcopy.hip).  Against the device-resident call's records, level by level, and the oracle's lake sizes at five levels.
+    import ctypes
+    import importlib
+    import torch
+    dev = importlib.import_module("rustronomy_watershed_amd.device")
+    eng = dev.DeviceEngine(0)
+    himg = ol.random_field(2048, 2048, 21)
+    hseeds = np.ascontiguousarray(np.asarray(ol.find_local_minima(himg), dtype=np.uint64).reshape(-1, 2))
+    img = torch.from_numpy(himg).to(eng.device)
+    seeds = torch.from_numpy(hseeds.astype(np.int64)).to(torch.int32).to(eng.device).contiguous()
+    d_lakes, d_off, d_unc = eng.transform_to_list(img, seeds, merging=True)
+    d_rec = d_lakes.cpu().numpy().astype(np.uint64)
+    ws = _merging(pkg)
+    c, L = ws._ctx(), pkg._ffi.lib()
+    cap = int(d_off[-1]) + 10
+    rec = np.zeros((cap, 2), dtype=np.uint64)
+    n_lakes = ctypes.c_size_t(0)
+    offsets, unc = np.zeros(256, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+    for threads in (4, 0):      # widened by host threads; one 16-byte copy per group, as before
+        assert L.ws_ctx_set_host_threads(c.handle, threads) == 0
+        rec[:] = 0
+        assert L.ws_transform_to_list(c.handle, 1, himg.ctypes.data, 2048, 2048, 2048, hseeds.ctypes.data, len(hseeds), ctypes.byref(ws._opt),
+                                      rec.ctypes.data, cap, ctypes.byref(n_lakes), offsets.ctypes.data, unc.ctypes.data) == 0
+        assert n_lakes.value == int(d_off[-1]) and (offsets == np.asarray(d_off, dtype=np.uint64)).all() and (unc == np.asarray(d_unc, dtype=np.uint64)).all()
+        for lvl in range(255):
+            a = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+            b = d_rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+            assert (a[np.argsort(a[:, 0])] == b[np.argsort(b[:, 0])]).all(), (threads, lvl)
+    want = {}
+    levels = (0, 40, 128, 200, 254)
+    ol.merge_arrival(himg, hseeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)) if l in levels else None)
+    for lvl in levels:
+        r = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+        nz = np.nonzero(want[lvl][1:])[0] + 1
+        assert unc[lvl] == want[lvl][0] and (np.sort(r[:, 0]) == nz).all() and (r[np.argsort(r[:, 0]), 1] == want[lvl][nz]).all(), lvl
