@@ -961,7 +961,20 @@ static int segment_tiled_host(ws_group *g, const uint8_t *img, size_t h, size_t 
                                          lists->offsets, lists->uncoloured);
       if (rc2 != WS_OK && rc2 != WS_ERR_CAPACITY) return gfail_if(g, me, rc2);
       const size_t got = std::min(*lists->n_lakes, lists->cap);
-      if (got) G_HIP(g, hipMemcpyAsync(lists->lakes, me.out64.p, got * sizeof(ws_lake), hipMemcpyDeviceToHost, s));
+      // (many records: narrowed to u32 on the device -- a colour and an area of a plane below 2^31 pixels fit -- and widened into
+      // the caller's ws_lake records by the host threads of rank 0's context, 8 M records a piece: half the bytes over the bus)
+      const size_t piece_max = (size_t)1 << 23;
+      if (got >= ((size_t)1 << 21) && ph * pw < 0x80000000ull) {
+        int rc3;
+        if ((rc3 = grow(g, me.rows, std::min(got, piece_max) * 2 * sizeof(uint32_t)))) return rc3;
+        for (size_t off = 0; off < got; off += piece_max) {
+          const size_t piece = std::min(piece_max, got - off);
+          G_HIP(g, narrow_words(s, (const uint64_t *)((const ws_lake *)me.out64.p + off), (uint32_t *)me.rows.p, 2 * piece));
+          G_WS(g, me, labels_to_host_u64(me.ctx, (const uint32_t *)me.rows.p, (uint64_t *)(lists->lakes + off), 2 * piece));
+        }
+      } else if (got) {
+        G_HIP(g, hipMemcpyAsync(lists->lakes, me.out64.p, got * sizeof(ws_lake), hipMemcpyDeviceToHost, s));
+      }
       G_HIP(g, hipStreamSynchronize(s));
       return gfail_if(g, me, rc2);
     }

@@ -458,6 +458,34 @@ def test_transform_to_list_of_a_host_field_over_a_group(pkg, n_ranks, edge):
     g.close()
 
 
+def test_host_lists_of_a_tiled_field_with_millions_of_records(pkg):
+    # from two million records on, rank 0's records reach the caller as u32 words widened by host threads, 8 M records a piece
+    # (ws_tiled.hip): 15 M records here -- two pieces -- against the one-context host call, level by level
+    ffi = pkg._ffi
+    himg = ol.random_field(1200, 1400, 3)
+    hseeds = np.ascontiguousarray(np.asarray(ol.find_local_minima(himg), dtype=np.uint64).reshape(-1, 2))
+    L = ffi.lib()
+    ws = pkg.api.TransformBuilder().build_merging()
+    c = ws._ctx()
+    cap = 17_000_000
+    a, b = np.zeros((cap, 2), dtype=np.uint64), np.zeros((cap, 2), dtype=np.uint64)
+    na, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    oa, ob = np.zeros(256, dtype=np.uint64), np.zeros(256, dtype=np.uint64)
+    ua, ub = np.zeros(255, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+    opt = ffi.Options(254)
+    assert L.ws_transform_to_list(c.handle, 1, himg.ctypes.data, 1200, 1400, 1400, hseeds.ctypes.data, len(hseeds), ctypes.byref(opt), a.ctypes.data, cap,
+                                  ctypes.byref(na), oa.ctypes.data, ua.ctypes.data) == 0
+    g = Group(pkg, 2)
+    rc = g.L.ws_transform_to_list_tiled(g.h, 1, himg.ctypes.data, 1200, 1400, 1400, hseeds.ctypes.data, len(hseeds), ctypes.byref(opt), b.ctypes.data, cap,
+                                        ctypes.byref(nb), ob.ctypes.data, ub.ctypes.data, None)
+    assert rc == 0, (rc, g.err())
+    assert na.value == nb.value > (1 << 23) and (oa == ob).all() and (ua == ub).all()
+    for lvl in range(255):
+        pa, pb = a[int(oa[lvl]):int(oa[lvl + 1])], b[int(ob[lvl]):int(ob[lvl + 1])]
+        assert (pa[np.argsort(pa[:, 0])] == pb[np.argsort(pb[:, 0])]).all(), lvl
+    g.close()
+
+
 def test_lists_from_the_arrival_planes_of_a_finished_transform(pkg):
     # ws_lists_from_arrival_device: transform_to_list without a second flood, from ws_last_arrival_device's stamps and the labels --
     # the same records as ws_transform_to_list_device on image and seeds, merging and segmenting; a padded plane as it stands
