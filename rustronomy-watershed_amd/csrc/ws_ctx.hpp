@@ -181,7 +181,8 @@ void stats_begin(ws_ctx *c);
 int stats_end(ws_ctx *c);
 // ws_hostcopy.hip: the device's u32 labels into a host caller's u64 plane, 4 bytes a pixel over the bus, widened by host threads
 // while the next chunks are in flight; returns with the copy complete (the stream has been waited for).
-int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t on = nullptr);      // on: another stream of the context's (default: its own)
+int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t on = nullptr,      // on: another stream of the context's (default: its own)
+                       size_t row_len = 0, size_t out_pitch = 0);      // row_len != 0: rows of row_len words to rows of out_pitch words (chunked road only: host_copy_in_chunks)
 void host_copy_release(ws_ctx *c);
 bool host_copy_in_chunks(const ws_ctx *c, size_t n);      // whether labels_to_host_u64 widens on the host (else: on the device, into c->out64)
 int check_plane(ws_ctx *c, size_t h, size_t w, size_t stride, const ws_options *opt, size_t *ph, size_t *pw);

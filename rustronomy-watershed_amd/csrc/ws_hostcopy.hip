@@ -107,10 +107,21 @@ static int one_copy(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n
   return WS_OK;
 }
 
-int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t on) {
+int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_t n, hipStream_t on, size_t row_len, size_t out_pitch) {
   const hipStream_t st = on ? on : c->stream;
   const int T = host_threads(c);
+  // (row_len != 0: the n words are rows of row_len that go to rows of out_pitch words in the caller's plane -- a tile's rectangle)
+  if (row_len != 0 && (!host_copy_in_chunks(c, n) || n % row_len != 0)) return fail(c, WS_ERR_BAD_ARG, "internal: a rectangle takes the chunked road or none");
   if (!host_copy_in_chunks(c, n)) return one_copy(c, d_labels, out, n, st);
+  // words [k0, k0 + len) of the packed source into their places in the caller's memory
+  auto widen_to = [&](const uint32_t *src, size_t k0, size_t len) {
+    if (row_len == 0) { widen_span(src, out + k0, len); return; }
+    while (len) {
+      const size_t r = k0 / row_len, col = k0 % row_len, run = std::min(len, row_len - col);
+      widen_span(src, out + r * out_pitch + col, run);
+      src += run; k0 += run; len -= run;
+    }
+  };
   if (int rc = host_copy_slots(c)) return rc;
   const size_t HC_CHUNK = chunk_of(n);
   const size_t nch = (n + HC_CHUNK - 1) / HC_CHUNK;
@@ -125,7 +136,7 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
       if (abort.load(std::memory_order_relaxed)) return;
       const size_t len = std::min(HC_CHUNK, n - i * HC_CHUNK);
       const size_t a = len * (size_t)t / (size_t)T, b = len * (size_t)(t + 1) / (size_t)T;
-      widen_span(stage + (i % HC_SLOTS) * HC_CHUNK + a, out + i * HC_CHUNK + a, b - a);
+      widen_to(stage + (i % HC_SLOTS) * HC_CHUNK + a, i * HC_CHUNK + a, b - a);
       done[i].fetch_add(1, std::memory_order_release);
     }
   };
@@ -142,7 +153,7 @@ int labels_to_host_u64(ws_ctx *c, const uint32_t *d_labels, uint64_t *out, size_
       const size_t len = std::min(HC_CHUNK, n - i * HC_CHUNK);
       HIP_TRY(c, hipMemcpyAsync(stage, d_labels + i * HC_CHUNK, len * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipStreamSynchronize(st));
-      widen_span(stage, out + i * HC_CHUNK, len);
+      widen_to(stage, i * HC_CHUNK, len);
     }
     return WS_OK;
   }

@@ -1063,7 +1063,13 @@ int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size
     if ((rc2 = tiled2d_rank(g, me, ph, pw, py, px, n_seeds, b, &plain, merging, &rounds[i]))) return rc2;
     // ---- the rectangle it owns, widened, into the caller's plane
     const size_t oh = r1 - r0, ow = c1 - c0;
-    if (oh * ow) {
+    if (oh * ow && host_copy_in_chunks(me.ctx, oh * ow)) {
+      // the rectangle packed on the device, over the bus as u32 chunks, widened into its rows of the caller's plane (ws_hostcopy.hip)
+      if ((rc2 = grow(g, me.rows, oh * ow * sizeof(uint32_t)))) return rc2;
+      G_HIP(g, hipMemcpy2DAsync(me.rows.p, ow * sizeof(uint32_t), (const uint32_t *)me.labels.p + (r0 - lo) * bw + (c0 - clo), bw * sizeof(uint32_t),
+                                ow * sizeof(uint32_t), oh, hipMemcpyDeviceToDevice, s));
+      G_WS(g, me, labels_to_host_u64(me.ctx, (const uint32_t *)me.rows.p, out_labels + r0 * pw + c0, oh * ow, nullptr, ow, pw));
+    } else if (oh * ow) {
       if ((rc2 = grow(g, me.out64, bn * sizeof(uint64_t)))) return rc2;
       G_HIP(g, widen_labels(s, (const uint32_t *)me.labels.p, (uint64_t *)me.out64.p, bn));
       G_HIP(g, hipMemcpy2DAsync(out_labels + r0 * pw + c0, pw * sizeof(uint64_t), (const uint64_t *)me.out64.p + (r0 - lo) * bw + (c0 - clo), bw * sizeof(uint64_t),

@@ -666,6 +666,28 @@ def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
     g.close()
 
 
+def test_2d_tiles_host_planes_of_more_than_two_million_pixels_a_tile(pkg):
+    # ws_segment_tiled2d with host buffers: a tile's owned rectangle is packed on the device, crosses the bus as u32 chunks and is
+    # widened into its rows of the caller's usize plane by host threads (ws_hostcopy.hip: rows of the rectangle to rows of the
+    # plane's pitch).  3000 x 2900 in 2 x 2 tiles (2.2 M pixels each) with edge correction, against the one-context host call.
+    ffi = pkg._ffi
+    L = ffi.lib()
+    himg = ol.random_field(3000, 2900, 9)
+    hseeds = np.ascontiguousarray(np.asarray(ol.find_local_minima(himg), dtype=np.uint64).reshape(-1, 2))
+    for edge in (False, True):
+        e = 2 if edge else 0
+        opt = ffi.Options(254, int(edge))
+        ws = pkg.api.TransformBuilder().build_segmenting()
+        want = np.zeros((3000 + e, 2900 + e), dtype=np.uint64)
+        assert L.ws_segment(ws._ctx().handle, himg.ctypes.data, 3000, 2900, 2900, hseeds.ctypes.data, len(hseeds), ctypes.byref(opt), want.ctypes.data) == 0
+        g = Group(pkg, 4)
+        got = np.full((3000 + e, 2900 + e), 7, dtype=np.uint64)
+        rc = g.L.ws_segment_tiled2d(g.h, himg.ctypes.data, 3000, 2900, 2900, hseeds.ctypes.data, len(hseeds), ctypes.byref(opt), 2, 2, 0, got.ctypes.data, None)
+        assert rc == 0, (rc, g.err())
+        assert (got == want).all()
+        g.close()
+
+
 @pytest.mark.parametrize("shape,py,px", [((2, 2), 2, 2), ((4, 4), 2, 2), ((3, 9), 1, 3), ((9, 3), 3, 1), ((5, 7), 2, 3), ((16, 1), 4, 1), ((1, 12), 1, 4), ((40, 33), 3, 2)])
 def test_2d_tiles_of_a_pixel_or_two(pkg, shape, py, px):
     # tiles whose planes are all halo, single rows and columns, fields smaller than a relaxation tile: segmenting and merging
