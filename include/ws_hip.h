@@ -517,6 +517,11 @@ typedef struct ws_tile_block2d {
 int ws_tile_grid(size_t h, size_t w, int rank, int py, int px, size_t *rows /* 4 */, size_t *cols /* 4 */);
 int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total,
                               const ws_tile_block2d *blocks, const ws_options *opt, int merging, uint32_t *exchange_rounds);
+/* transform_to_list of a field in py x px tiles: ws_transform_to_list_tiled_device with the owned rectangles gathered on rank 0. */
+int ws_transform_to_list_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total,
+                                        const ws_tile_block2d *blocks, const ws_options *opt, int merging, ws_lake *d_lakes,
+                                        size_t cap, size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured,
+                                        uint32_t *exchange_rounds);
 /* ... with host buffers in and out, as ws_segment_tiled: every rank of the group calls it with the SAME arguments, uploads its
  * tile, takes its seeds (any list), writes the rectangle it owns of out_labels.  Edge correction pads the field first. */
 int ws_segment_tiled2d(ws_group *g, const uint8_t *img, size_t h, size_t w, size_t row_stride, const uint64_t *seeds_rc,

@@ -258,6 +258,9 @@ extern "C" {
     pub fn ws_tile_grid(h: usize, w: usize, rank: c_int, py: c_int, px: c_int, rows: *mut usize, cols: *mut usize) -> c_int;
     pub fn ws_segment_tiled2d_device(g: *mut ws_group, field_h: usize, field_w: usize, py: c_int, px: c_int, n_seeds_total: usize,
         blocks: *const ws_tile_block2d, opt: *const ws_options, merging: c_int, exchange_rounds: *mut u32) -> c_int;
+    pub fn ws_transform_to_list_tiled2d_device(g: *mut ws_group, field_h: usize, field_w: usize, py: c_int, px: c_int, n_seeds_total: usize, blocks: *const ws_tile_block2d,
+                                               opt: *const ws_options, merging: c_int, d_lakes: *mut ws_lake, cap: usize, n_lakes: *mut usize, offsets: *mut u64,
+                                               uncoloured: *mut u64, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_tiled2d(g: *mut ws_group, img: *const u8, h: usize, w: usize, row_stride: usize, seeds_rc: *const u64,
         n_seeds: usize, opt: *const ws_options, py: c_int, px: c_int, merging: c_int, out_labels: *mut u64, exchange_rounds: *mut u32) -> c_int;
     pub fn ws_segment_batch_group(g: *mut ws_group, h: usize, w: usize, parts: *const ws_batch_part, opt: *const ws_options,

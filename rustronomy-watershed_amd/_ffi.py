@@ -161,6 +161,7 @@ SIGNATURES = {
     "ws_transform_to_list_tiled_device": (ctypes.c_int, [vp, sz, sz, sz, vp, ctypes.POINTER(Options), ctypes.c_int, vp, sz, szp, vp, vp, u32p]),
     "ws_tile_grid": (ctypes.c_int, [sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, szp, szp]),
     "ws_segment_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(TileBlock2D), ctypes.POINTER(Options), ctypes.c_int, u32p]),
+    "ws_transform_to_list_tiled2d_device": (ctypes.c_int, [vp, sz, sz, ctypes.c_int, ctypes.c_int, sz, vp, ctypes.POINTER(Options), ctypes.c_int, vp, sz, szp, vp, vp, u32p]),
     "ws_segment_tiled2d": (ctypes.c_int, [vp, vp, sz, sz, sz, vp, sz, ctypes.POINTER(Options), ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, u32p]),
     "ws_segment_batch_group": (ctypes.c_int, [vp, sz, sz, ctypes.POINTER(BatchPart), ctypes.POINTER(Options), szp, szp]),
 }

@@ -259,6 +259,67 @@ struct Exchange {
     return WS_OK;
   }
 
+  // ... of a field in py x px tiles: every rank's OWNED rectangle of its plane (pitch bw, first row lo, first column clo of the
+  // field) -> rank 0's whole plane (field_h x field_w).  A rectangle travels packed (me.rows); rank 0 parks what it receives in
+  // me.table and places every rectangle with a 2-D copy.  Returns with rank 0's copies complete.
+  int gather_rect(const uint32_t *plane, size_t bw, size_t field_h, size_t field_w, int py, int px, uint32_t *full) {
+    size_t rows[4], cols[4];
+    if (ws_tile_grid(field_h, field_w, me.rank, py, px, rows, cols)) return gfail(g, WS_ERR_BAD_ARG, "bad tile grid");
+    const size_t oh = rows[1] - rows[0], ow = cols[1] - cols[0];
+    int rc;
+    if ((rc = grow(g, me.rows, std::max<size_t>(oh * ow, 1) * sizeof(uint32_t)))) return rc;
+    if (oh * ow)
+      G_HIP(g, hipMemcpy2DAsync(me.rows.p, ow * sizeof(uint32_t), plane + (rows[0] - rows[2]) * bw + (cols[0] - cols[2]), bw * sizeof(uint32_t),
+                                ow * sizeof(uint32_t), oh, hipMemcpyDeviceToDevice, stream()));
+    auto place = [&](int r, const uint32_t *packed) -> int {      // rank r's packed rectangle into the whole plane
+      size_t rr[4], cc[4];
+      (void)ws_tile_grid(field_h, field_w, r, py, px, rr, cc);
+      const size_t h2 = rr[1] - rr[0], w2 = cc[1] - cc[0];
+      if (h2 * w2)
+        G_HIP(g, hipMemcpy2DAsync(full + rr[0] * field_w + cc[0], field_w * sizeof(uint32_t), packed, w2 * sizeof(uint32_t), w2 * sizeof(uint32_t), h2,
+                                  hipMemcpyDeviceToDevice, stream()));
+      return WS_OK;
+    };
+    if (g->is_rccl) {
+      RcclApi *n = rccl();
+      std::vector<size_t> at((size_t)g->world + 1, 0);
+      if (me.rank == 0) {
+        for (int r = 1; r < g->world; ++r) {
+          size_t rr[4], cc[4];
+          (void)ws_tile_grid(field_h, field_w, r, py, px, rr, cc);
+          at[(size_t)r + 1] = at[(size_t)r] + (rr[1] - rr[0]) * (cc[1] - cc[0]);
+        }
+        if ((rc = grow(g, me.table, std::max<size_t>(at[(size_t)g->world], 1) * sizeof(uint32_t)))) return rc;
+      }
+      G_NCCL(g, n->GroupStart());
+      if (me.rank != 0) {
+        if (oh * ow) G_NCCL(g, n->Send(me.rows.p, oh * ow, ncclUint32, 0, g->comm, stream()));
+      } else {
+        for (int r = 1; r < g->world; ++r)
+          if (at[(size_t)r + 1] > at[(size_t)r])
+            G_NCCL(g, n->Recv((uint32_t *)me.table.p + at[(size_t)r], at[(size_t)r + 1] - at[(size_t)r], ncclUint32, r, g->comm, stream()));
+      }
+      G_NCCL(g, n->GroupEnd());
+      if (me.rank == 0) {
+        if ((rc = place(0, (const uint32_t *)me.rows.p))) return rc;
+        for (int r = 1; r < g->world; ++r)
+          if ((rc = place(r, (const uint32_t *)me.table.p + at[(size_t)r]))) return rc;
+      }
+      G_HIP(g, hipStreamSynchronize(stream()));
+      return WS_OK;
+    }
+    G_HIP(g, hipStreamSynchronize(stream()));      // my packed rectangle is complete before rank 0 copies it
+    me.pub_send = (const uint32_t *)me.rows.p;
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    if (me.rank == 0) {
+      for (int r = 0; r < g->world; ++r)
+        if ((rc = place(r, local(r)->pub_send))) return rc;
+      G_HIP(g, hipStreamSynchronize(stream()));
+    }
+    if (!g->barrier.wait()) return gfail(g, WS_ERR_HIP, "another rank of the group failed");
+    return WS_OK;
+  }
+
   // max (or min) over the ranks of the word at me.flag[0]; stream ordered behind whatever wrote it; ONE host read
   int reduce(bool take_max, uint32_t *result) {
     if (g->is_rccl) {
@@ -840,6 +901,51 @@ int ws_segment_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int p
   rc = for_local_ranks(g, [&](Rank &me) {
     const size_t i = (size_t)(me.rank - g->first_local);
     return tiled2d_rank(g, me, field_h, field_w, py, px, n_seeds_total, blocks[i], opt, merging, &rounds[i]);
+  });
+  if (exchange_rounds) *exchange_rounds = rounds[0];
+  return rc;
+}
+
+// transform_to_list of a field in py x px tiles: as ws_transform_to_list_tiled_device, the owned RECTANGLES gathered on rank 0
+int ws_transform_to_list_tiled2d_device(ws_group *g, size_t field_h, size_t field_w, int py, int px, size_t n_seeds_total,
+                                        const ws_tile_block2d *blocks, const ws_options *opt, int merging, ws_lake *d_lakes, size_t cap,
+                                        size_t *n_lakes, uint64_t *offsets, uint64_t *uncoloured, uint32_t *exchange_rounds) {
+  int rc = check_group_call(g, opt);
+  if (rc) return rc;
+  if (!blocks || !n_lakes || !offsets || !uncoloured) return gfail(g, WS_ERR_BAD_ARG, "null pointer");
+  if (py < 1 || px < 1 || py * px != g->world) return gfail(g, WS_ERR_BAD_ARG, "py * px must be the group's number of ranks");
+  if (opt->edge_correction) return gfail(g, WS_ERR_UNSUPPORTED, "the tiled transforms take the field as it is: pad it first");
+  if (field_h < (size_t)py || field_w < (size_t)px) return gfail(g, WS_ERR_BAD_ARG, "a field needs at least one row and one column per tile");
+  if (n_seeds_total >= 0x7FFFFFFFull) return gfail(g, WS_ERR_TOO_LARGE, "colours must stay below 2^31");
+  if (g->first_local == 0 && !d_lakes && cap) return gfail(g, WS_ERR_BAD_ARG, "d_lakes is null");
+  for (size_t i = 0; i < g->ranks.size(); ++i) {
+    const ws_tile_block2d &b = blocks[i];
+    size_t rws[4], cls[4];
+    if (ws_tile_grid(field_h, field_w, g->first_local + (int)i, py, px, rws, cls)) return gfail(g, WS_ERR_BAD_ARG, "bad tile grid");
+    if (!b.d_img || !b.d_labels || b.img_stride < cls[3] - cls[2] || (b.n_seeds && (!b.d_seeds_rc || !b.d_colours)))
+      return gfail(g, WS_ERR_BAD_ARG, "bad block descriptor");
+  }
+  *n_lakes = 0;
+  if (exchange_rounds) *exchange_rounds = 0;
+  std::vector<uint32_t> rounds(g->ranks.size(), 0);
+  rc = for_local_ranks(g, [&](Rank &me) -> int {
+    const size_t i = (size_t)(me.rank - g->first_local);
+    int rc2;
+    if ((rc2 = tiled2d_rank(g, me, field_h, field_w, py, px, n_seeds_total, blocks[i], opt, 0, &rounds[i]))) return rc2;
+    size_t rows[4], cols[4];
+    (void)ws_tile_grid(field_h, field_w, me.rank, py, px, rows, cols);
+    const size_t bw = cols[3] - cols[2], n = field_h * field_w;
+    if (me.rank == 0) {
+      if ((rc2 = grow(g, me.full_keys, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+      if ((rc2 = grow(g, me.full_labels, (n ? n : 1) * sizeof(uint32_t)))) return rc2;
+    }
+    Exchange x{g, me};
+    G_HIP(g, hipStreamSynchronize(me.ctx->stream));
+    if ((rc2 = x.gather_rect((const uint32_t *)me.keys.p, bw, field_h, field_w, py, px, (uint32_t *)me.full_keys.p))) return rc2;
+    if ((rc2 = x.gather_rect(blocks[i].d_labels, bw, field_h, field_w, py, px, (uint32_t *)me.full_labels.p))) return rc2;
+    if (me.rank != 0) return WS_OK;
+    return gfail_if(g, me, ws_lists_from_arrival_device(me.ctx, merging, (const uint32_t *)me.full_keys.p, (const uint32_t *)me.full_labels.p, field_h, field_w,
+                                                        n_seeds_total, opt, d_lakes, cap, n_lakes, offsets, uncoloured));
   });
   if (exchange_rounds) *exchange_rounds = rounds[0];
   return rc;

@@ -666,6 +666,43 @@ def test_2d_tiles_at_size_and_through_an_rccl_group_of_one(pkg):
     g.close()
 
 
+@pytest.mark.parametrize("py,px", [(2, 2), (2, 3), (1, 4), (3, 1)])
+@pytest.mark.parametrize("merging", [True, False])
+def test_transform_to_list_of_a_field_in_2d_tiles(pkg, py, px, merging):
+    # ws_transform_to_list_tiled2d_device: the flood in py x px tiles, the owned rectangles of stamps and labels gathered on rank 0,
+    # the records of all levels from the whole plane there.  Lake sizes of every level against the oracle's.
+    import torch
+    grp_mod = importlib.import_module("rustronomy_watershed_amd.group")
+    ffi = pkg._ffi
+    dev = torch.device("cuda", 0)
+    for kind in ("noise", "smooth"):
+        H, W = (190, 230) if kind == "noise" else (170, 150)
+        himg = cases.field(H, W, 13) if kind == "noise" else cases.smooth_field(H, W, 5, octaves=4)
+        hseeds = np.asarray(ol.find_local_minima(himg), dtype=np.int64).reshape(-1, 2)
+        want = {}
+        (ol.merge_arrival if merging else ol.segment)(himg, hseeds, hook=lambda l, m, i, c: want.__setitem__(l, ol.find_lake_sizes(c)))
+        g = grp_mod.Group.local(py * px)
+        field = torch.from_numpy(himg).to(dev)
+        s = torch.from_numpy(hseeds.astype(np.int32)).to(dev)
+        blocks, spans, keep = g.make_blocks2d(field, s, py, px)
+        cap = 255 * (len(hseeds) + 1)
+        lakes = torch.zeros((cap, 2), dtype=torch.int64, device=dev)
+        n_lakes = ctypes.c_size_t(0)
+        offsets, uncol = np.zeros(256, dtype=np.uint64), np.zeros(255, dtype=np.uint64)
+        opt = ffi.Options(254)
+        rc = ffi.lib().ws_transform_to_list_tiled2d_device(g._h, H, W, py, px, len(hseeds), blocks, ctypes.byref(opt), int(merging), lakes.data_ptr(), cap,
+                                                           ctypes.byref(n_lakes), offsets.ctypes.data, uncol.ctypes.data, None)
+        assert rc == 0, (rc, ffi.lib().ws_group_last_error(g._h))
+        rec = lakes.cpu().numpy()
+        for lvl in range(255):
+            dense = np.zeros(H * W + 1, dtype=np.uint64)
+            part = rec[int(offsets[lvl]):int(offsets[lvl + 1])]
+            dense[part[:, 0]] = part[:, 1].astype(np.uint64)
+            dense[0] = uncol[lvl]
+            assert (dense == want[lvl]).all(), (kind, lvl)
+        g.close()
+
+
 def test_2d_tiles_host_planes_of_more_than_two_million_pixels_a_tile(pkg):
     # ws_segment_tiled2d with host buffers: a tile's owned rectangle is packed on the device, crosses the bus as u32 chunks and is
     # widened into its rows of the caller's usize plane by host threads (ws_hostcopy.hip: rows of the rectangle to rows of the
