@@ -787,6 +787,33 @@ int ws_group_selftest(ws_group *g) {
         }
       }
     }
+    // ... and of owned rectangles (transform_to_list of a field in tiles): a field of 3 x (2 * world + 1) words cut into 1 x world
+    // tiles, every word rank * 100000 + its index in the field
+    {
+      const size_t fh = 3, fw = 2 * (size_t)world + 1;
+      size_t rows[4], cols[4];
+      if (ws_tile_grid(fh, fw, me.rank, 1, world, rows, cols)) return gfail(g, WS_ERR_BAD_ARG, "selftest: tile grid");
+      const size_t bh = rows[3] - rows[2], bw = cols[3] - cols[2];
+      std::vector<uint32_t> plane(bh * bw, 0xDEADu), full(fh * fw);
+      for (size_t r = rows[0]; r < rows[1]; ++r)
+        for (size_t q = cols[0]; q < cols[1]; ++q) plane[(r - rows[2]) * bw + (q - cols[2])] = (uint32_t)me.rank * 100000u + (uint32_t)(r * fw + q);
+      if ((rc = grow(g, me.keys, std::max<size_t>(plane.size(), h * w) * sizeof(uint32_t)))) return rc;
+      if (me.rank == 0 && (rc = grow(g, me.full_keys, std::max<size_t>(fh * fw, (2 * (size_t)world + 1) * w) * sizeof(uint32_t)))) return rc;
+      G_HIP(g, hipMemcpyAsync(me.keys.p, plane.data(), plane.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+      G_HIP(g, hipStreamSynchronize(s));
+      if ((rc = x.gather_rect((const uint32_t *)me.keys.p, bw, fh, fw, 1, world, (uint32_t *)me.full_keys.p))) return rc;
+      if (me.rank == 0) {
+        G_HIP(g, hipMemcpyAsync(full.data(), me.full_keys.p, fh * fw * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        G_HIP(g, hipStreamSynchronize(s));
+        for (int k = 0; k < world; ++k) {
+          size_t rr[4], cc[4];
+          (void)ws_tile_grid(fh, fw, k, 1, world, rr, cc);
+          for (size_t r = rr[0]; r < rr[1]; ++r)
+            for (size_t q = cc[0]; q < cc[1]; ++q)
+              if (full[r * fw + q] != (uint32_t)k * 100000u + (uint32_t)(r * fw + q)) return gfail(g, g->is_rccl ? WS_ERR_RCCL : WS_ERR_HIP, "selftest: the gather of owned rectangles on rank 0 delivered wrong words");
+        }
+      }
+    }
     return WS_OK;
   });
 }
